@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s scanned (48 kHz stereo f32), BASELINE.json.
+
+  python bench.py [--gpus N --steps K --warmup W]            # N = 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): per GPU one synthetic
+60 min 48 kHz stereo f32 buffer (172 800 000 frames, 1 382 400 000 B) resident
+in HBM; one "step" = one full EBU R128 scan of it: K-weighting + 100 ms block
+energies + sample peak kernel, gating / LRA epilogue (true peak off = C2; pass
+--workload c3 for the reference's always-on true peak).  With N > 1 every rank
+scans its own buffer as one track of an N-track album and each step ends with
+the album reduction over RCCL (weak scaling).  `value` = samples of all ranks /
+max-over-ranks wall time of K steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def cpu_baseline(pcm_host, rate, seconds):
+    """CPU restatement of the reference path (oracle/, scan.c + libebur128 1.2.4
+    semantics, all five modes on as scan.c:203-207), 1 thread, bounded sample."""
+    from oracle import lgoracle
+    import numpy as np
+    lgoracle.lib()
+    st = lgoracle.State(pcm_host.shape[1], rate)
+    t0 = time.perf_counter()
+    st.add(pcm_host, chunk=4096)
+    loud = st.loudness()
+    st.lra()
+    st.peak()
+    dt = time.perf_counter() - t0
+    return dict(value=round(pcm_host.size / dt / 1e6, 2), unit="Msamples/s", cores=1, kind="port",
+                sample="first %d s of the same buffer, 1 thread, oracle -O2, all modes incl. 4x true peak "
+                       "(CPU restatement of reference path); %.2f s wall; %.3f LUFS" % (seconds, dt, loud))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--minutes", type=float, default=60.0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--seg-subblocks", type=int, default=0)
+    ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--warm-subblocks", type=int, default=-1)
+    ap.add_argument("--cpu-seconds", type=int, default=1800)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from loudgain_amd import synth
+    from loudgain_amd.device import DeviceScanner
+    from loudgain_amd.album import DistributedAlbumScanner
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rate, ch = 48000, 2
+    frames = int(round(args.minutes * 60 * rate))
+    true_peak = args.workload == "c3"
+    pcm = synth.track_torch(frames, ch, rate, seed=rank, device=dev)
+    torch.cuda.synchronize()
+
+    sc = DeviceScanner(local_rank)
+    if args.chunk:
+        sc.set_param("chunk", args.chunk)
+    if args.seg_subblocks:
+        sc.set_param("seg_subblocks", args.seg_subblocks)
+    if args.waves_per_cu:
+        sc.set_param("waves_per_cu", args.waves_per_cu)
+    if args.warm_subblocks >= 0:
+        sc.set_param("warm_subblocks", args.warm_subblocks)
+    stream = torch.cuda.Stream(device=dev)
+    if world > 1:
+        job = DistributedAlbumScanner(sc, [pcm], rate, true_peak=true_peak)
+    else:
+        job = sc.plan([pcm], rate, true_peak=true_peak, album=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.execute(stream)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.execute(stream)
+    results = job.fetch()  # synchronises the stream, copies the numbers out
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samples_per_step = frames * ch * world
+    value = samples_per_step * args.steps / dt / 1e6
+    ks = sc.kernel_ms_stats(min(args.steps, 64))
+    info = sc.plan_info()
+    algo_bytes = frames * ch * 4  # 4 B read per sample, writes ~ 0
+    achieved = algo_bytes / (ks["scan_mean_ms"] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        tr = results[0][0]
+        line = {
+            "metric": "Msamples/s scanned (48 kHz stereo f32)",
+            "value": round(value, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %g min 48 kHz stereo f32 per GPU, K-filter + gated loudness + LRA%s%s"
+                            % (args.workload.upper(), args.minutes,
+                               " + 4x true peak" if true_peak else ", no true peak",
+                               "; %d-track album, RCCL album reduce per step" % world if world > 1 else ""),
+                "frames_per_gpu": frames, "channels": ch, "rate": rate,
+                "chunk": info["chunk"], "segments": info["segments"],
+                "x_realtime": round(value * 1e6 / (rate * ch), 0),
+                "mframes_per_s": round(value / ch, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "lgd_scan_kernel", "kernel_ms_mean": round(ks["scan_mean_ms"], 4),
+                "kernel_ms_min": round(ks["scan_min_ms"], 4), "launches_timed": ks["n"],
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "enqueue_total_ms_mean": round(ks["total_mean_ms"], 4),
+            },
+            "result": {"loudness": tr["loudness"], "lra": tr["lra"], "peak": tr["peak"],
+                       "n_abs": tr["n_abs"], "n_rel": tr["n_rel"], "n_st": tr["n_st"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            secs = int(min(args.cpu_seconds, args.minutes * 60))
+            host = pcm[: secs * rate].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(host, rate, secs)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/*
+ * loudscan_device.h -- device-level C ABI of the MI355X EBU R128 scanner.
+ *
+ * Plain C, plain pointers and sizes: this is the inner boundary that the
+ * scan.h drop-in (include/loudscan.h) and every FFI binding (ctypes, cgo, JNI)
+ * call.  It replaces what /root/reference/src/scan.c obtains from libebur128:
+ *
+ *   lgd_plan            <- ebur128_init per file            scan.c:203-207
+ *   lgd_execute         <- ebur128_add_frames_short loop    scan.c:225-250,448
+ *   lgd_fetch (track)   <- ebur128_loudness_global          scan.c:294
+ *                          ebur128_loudness_range           scan.c:297
+ *                          ebur128_true_peak per channel    scan.c:300-307
+ *   lgd_fetch (album)   <- ebur128_loudness_global_multiple scan.c:383
+ *                          ebur128_loudness_range_multiple  scan.c:388
+ *                          album peak loop                  scan.c:359-378
+ *
+ * PCM is interleaved f32 resident in HBM (scale 1.0 == ebur128_add_frames_float;
+ * values on the S16 grid k/32768 reproduce the reference's S16 feed, scan.c:414).
+ * Every call returns 0 on success or a negative LGD_E* code; lgd_last_error()
+ * gives the text.  No call falls back to a CPU implementation.
+ */
+#ifndef LOUDSCAN_DEVICE_H
+#define LOUDSCAN_DEVICE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGD_MAX_CHANNELS 64 /* ebur128_init rejects > 64 */
+
+enum {
+  LGD_OK = 0,
+  LGD_EINVAL = -1,  /* bad argument (channels 0 / > 64, rate < 16 / > 2822400, ...) */
+  LGD_ENOMEM = -2,  /* hipMalloc failed */
+  LGD_EHIP = -3,    /* HIP runtime / launch error */
+  LGD_ESTATE = -4,  /* call order violated (execute before plan, ...) */
+  LGD_EUNSUP = -5   /* configuration the kernels do not cover */
+};
+
+enum {
+  LGD_FLAG_TRUE_PEAK = 1u << 0, /* oversampled true peak (always on in the reference) */
+  LGD_FLAG_ALBUM = 1u << 1,     /* also run the album reductions (scan.c:380-405) */
+  LGD_FLAG_ALBUM_PART1 = 1u << 2 /* multi-GPU album: stop after this rank's part1; the
+                                    caller exchanges partials and drives stages 2 and 3 */
+};
+
+typedef struct lgd_ctx lgd_ctx;
+
+/* one input file == one ebur128_state in the reference (scan.c:126) */
+typedef struct {
+  const float *pcm;  /* device pointer, interleaved f32, 16-byte aligned */
+  uint64_t frames;   /* frames (samples per channel) */
+  uint32_t channels; /* 1..64; default libebur128 channel map by index */
+  uint32_t rate;     /* Hz */
+} lgd_track;
+
+typedef struct {
+  double loudness;       /* LUFS; -HUGE_VAL when no block passes the gates */
+  double lra;            /* LU; 0.0 when no short-term block is listed */
+  double peak;           /* max over channels of max(true peak, sample peak) */
+  double sample_peak;    /* max over channels */
+  double true_peak;      /* max over channels of the interpolated peak (0 if off) */
+  double rel_threshold;  /* relative gate, energy units */
+  double sum_abs;        /* sum of block energies >= absolute gate */
+  double sum_rel;        /* sum of block energies >= relative gate */
+  uint64_t n_blocks;     /* 400 ms blocks evaluated */
+  uint64_t n_abs;        /* blocks >= absolute gate (the reference's list length) */
+  uint64_t n_rel;        /* blocks >= relative gate */
+  uint64_t n_st_blocks;  /* 3 s blocks evaluated */
+  uint64_t n_st;         /* 3 s blocks >= absolute gate */
+} lgd_track_result;
+
+typedef struct {
+  double loudness, lra, peak, rel_threshold, sum_abs, sum_rel;
+  uint64_t n_abs, n_rel, n_st;
+} lgd_album_result;
+
+/* album partials exchanged between GPUs (one RCCL all-reduce each) */
+typedef struct {
+  double sum_abs; /* all-reduce SUM */
+  double n_abs;   /* all-reduce SUM (integer-valued, exact below 2^53) */
+  double peak;    /* all-reduce MAX */
+  double n_st;    /* all-reduce SUM */
+} lgd_album_part1;
+typedef struct {
+  double sum_rel; /* all-reduce SUM */
+  double n_rel;   /* all-reduce SUM */
+} lgd_album_part2;
+
+lgd_ctx *lgd_create(int device);
+void lgd_destroy(lgd_ctx *ctx);
+const char *lgd_last_error(void);
+
+/* tuning knobs: "chunk" (frames per lane, 0 = auto), "seg_subblocks" (100 ms
+ * sub-blocks per wave segment, 0 = auto), "warm_subblocks" (K-filter warm-up
+ * before a segment, default 3), "waves_per_cu" (auto segmentation target). */
+int lgd_set_param(lgd_ctx *ctx, const char *name, long value);
+
+/* Build the segment table + workspace for a batch of tracks (host work and
+ * hipMalloc happen here, never in lgd_execute). */
+int lgd_plan(lgd_ctx *ctx, const lgd_track *tracks, uint32_t n_tracks, uint32_t flags);
+/* Enqueue the whole scan on `hip_stream` (hipStream_t as void*; NULL = default
+ * stream): K-weight + block-energy + peak kernel(s), gating / LRA epilogue and,
+ * with LGD_FLAG_ALBUM, the album stages.  Asynchronous, no allocation. */
+int lgd_execute(lgd_ctx *ctx, void *hip_stream);
+/* Synchronise the stream used by the last lgd_execute and copy results out.
+ * `album` may be NULL. */
+int lgd_fetch(lgd_ctx *ctx, lgd_track_result *tracks_out, lgd_album_result *album);
+
+/* Multi-GPU album: lgd_execute() leaves this rank's part1 in the ctx; exchange
+ * it (device pointers, all-reduce in place), then run stage 2, exchange part2,
+ * gather the short-term energies and finish with stage 3. */
+int lgd_album_part1_ptr(lgd_ctx *ctx, lgd_album_part1 **dev_ptr);
+int lgd_album_part2_ptr(lgd_ctx *ctx, lgd_album_part2 **dev_ptr);
+int lgd_album_stage2(lgd_ctx *ctx, void *hip_stream);
+/* this rank's listed short-term energies (unlisted slots hold 0.0) */
+int lgd_album_st_ptr(lgd_ctx *ctx, double **dev_ptr, uint64_t *n_slots);
+/* st_all: device array of n_slots energies gathered from all ranks (or NULL to
+ * use this rank's own). */
+int lgd_album_stage3(lgd_ctx *ctx, const double *st_all, uint64_t n_slots, void *hip_stream);
+
+/* per-track block energies for parity tests: 100 ms sub-block energies
+ * (sum_c w_c sum y^2, not yet divided by the block length) */
+int lgd_copy_subblock_energies(lgd_ctx *ctx, uint32_t track, double *host_out, uint64_t cap,
+                               uint64_t *n_out);
+/* kernel-only timing of the last lgd_execute on its stream (hipEvents recorded
+ * on that stream around the dominant kernel and around the whole enqueue) */
+int lgd_last_kernel_ms(lgd_ctx *ctx, float *scan_ms, float *total_ms);
+/* the same over the last `last_n` (<= 64, 0 = 64) executes: mean / min of the scan
+ * kernel, mean of the whole enqueue; synchronises on their events */
+int lgd_kernel_ms_stats(lgd_ctx *ctx, uint32_t last_n, float *scan_mean, float *scan_min,
+                        float *total_mean, uint32_t *n_used);
+/* plan geometry (for DESIGN/bench reporting) */
+int lgd_plan_info(lgd_ctx *ctx, uint64_t *n_segments, uint64_t *n_subblocks, uint32_t *chunk,
+                  uint64_t *pcm_bytes, uint64_t *warm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,90 @@
+"""Loads libloudscan_hip.so and declares the C ABI of include/loudscan_device.h."""
+import ctypes as C
+import os
+
+from .build import LIB
+
+_L = None
+
+
+class LgdTrack(C.Structure):
+    _fields_ = [("pcm", C.c_void_p), ("frames", C.c_uint64), ("channels", C.c_uint32),
+                ("rate", C.c_uint32)]
+
+
+class LgdTrackResult(C.Structure):
+    _fields_ = [("loudness", C.c_double), ("lra", C.c_double), ("peak", C.c_double),
+                ("sample_peak", C.c_double), ("true_peak", C.c_double),
+                ("rel_threshold", C.c_double), ("sum_abs", C.c_double), ("sum_rel", C.c_double),
+                ("n_blocks", C.c_uint64), ("n_abs", C.c_uint64), ("n_rel", C.c_uint64),
+                ("n_st_blocks", C.c_uint64), ("n_st", C.c_uint64)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class LgdAlbumResult(C.Structure):
+    _fields_ = [("loudness", C.c_double), ("lra", C.c_double), ("peak", C.c_double),
+                ("rel_threshold", C.c_double), ("sum_abs", C.c_double), ("sum_rel", C.c_double),
+                ("n_abs", C.c_uint64), ("n_rel", C.c_uint64), ("n_st", C.c_uint64)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+FLAG_TRUE_PEAK = 1
+FLAG_ALBUM = 2
+FLAG_ALBUM_PART1 = 4
+
+# every symbol include/loudscan_device.h declares
+DEVICE_SYMBOLS = [
+    "lgd_create", "lgd_destroy", "lgd_last_error", "lgd_set_param", "lgd_plan", "lgd_execute",
+    "lgd_fetch", "lgd_album_part1_ptr", "lgd_album_part2_ptr", "lgd_album_stage2",
+    "lgd_album_st_ptr", "lgd_album_stage3", "lgd_copy_subblock_energies", "lgd_last_kernel_ms",
+    "lgd_kernel_ms_stats", "lgd_plan_info",
+]
+
+
+def load():
+    """The product path has no fallback: a missing library is a hard error."""
+    global _L
+    if _L is not None:
+        return _L
+    if not os.path.exists(LIB):
+        raise RuntimeError(
+            "libloudscan_hip.so is not built (%s). Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback." % LIB)
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64
+    # (same soname as /opt/rocm's).  Whichever is mapped first is shared by the
+    # other only if torch comes first, so import torch before our library; a
+    # second runtime in the process would see no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB)
+    vp = C.c_void_p
+    L.lgd_create.restype = vp
+    L.lgd_create.argtypes = [C.c_int]
+    L.lgd_destroy.argtypes = [vp]
+    L.lgd_destroy.restype = None
+    L.lgd_last_error.restype = C.c_char_p
+    L.lgd_set_param.argtypes = [vp, C.c_char_p, C.c_long]
+    L.lgd_plan.argtypes = [vp, C.POINTER(LgdTrack), C.c_uint32, C.c_uint32]
+    L.lgd_execute.argtypes = [vp, vp]
+    L.lgd_fetch.argtypes = [vp, C.POINTER(LgdTrackResult), C.POINTER(LgdAlbumResult)]
+    L.lgd_album_part1_ptr.argtypes = [vp, C.POINTER(vp)]
+    L.lgd_album_part2_ptr.argtypes = [vp, C.POINTER(vp)]
+    L.lgd_album_stage2.argtypes = [vp, vp]
+    L.lgd_album_st_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.lgd_album_stage3.argtypes = [vp, vp, C.c_uint64, vp]
+    L.lgd_copy_subblock_energies.argtypes = [vp, C.c_uint32, vp, C.c_uint64,
+                                             C.POINTER(C.c_uint64)]
+    L.lgd_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.lgd_kernel_ms_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.lgd_plan_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                C.POINTER(C.c_uint64)]
+    _L = L
+    return L

@@ -1,0 +1,586 @@
+// lgd_engine.cpp -- host side of the device-level C ABI (include/loudscan_device.h).
+//
+// Plans a batch of tracks into wavefront-sized segments, owns the HBM
+// workspace, enqueues the kernels of lgd_kernels.hip and copies results out.
+// Replaces what /root/reference/src/scan.c gets from libebur128:
+// ebur128_init (scan.c:203) -> lgd_plan, the add_frames loop (scan.c:225-250,
+// :448) -> lgd_execute, the loudness/range/peak queries (scan.c:294-307,
+// :383-391, :359-378) -> lgd_fetch.  There is no CPU fallback anywhere here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/loudscan_device.h"
+#include "lgd_internal.h"
+
+extern "C" const int lgd_chunk_table[];
+extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
+                                      const LgdFilt *F, hipStream_t s);
+extern "C" hipError_t lgd_launch_track_epilogue(const LgdTrackMeta *meta, int n_tracks,
+                                                const double *E, double *st, const float *peaks,
+                                                double *res, double abs_gate, double rel_factor,
+                                                int do_tp, hipStream_t s);
+extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
+                                     double minus20, hipStream_t s);
+extern "C" hipError_t lgd_launch_album_part1(const double *res, int n_tracks, double *part1,
+                                             hipStream_t s);
+extern "C" hipError_t lgd_launch_album_stage2(const LgdTrackMeta *meta, int n_tracks,
+                                              const double *E, double *res, const double *part1,
+                                              double *part2, double abs_gate, double rel_factor,
+                                              hipStream_t s);
+extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *part2,
+                                             double rel_factor, double *album, hipStream_t s);
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                    \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(e_ == hipErrorOutOfMemory ? LGD_ENOMEM : LGD_EHIP, "%s: %s", #expr,   \
+                  hipGetErrorString(e_));                                               \
+  } while (0)
+
+// ------------------------------------------------------------ filter design --
+// BS.1770 K-weighting as libebur128 designs it for an arbitrary rate
+// (SURVEY.md A.1): high-shelf biquad pb/pa and RLB high-pass (1,-2,1)/ra.  The
+// library merges them into one 4th-order filter; the kernels keep the chain.
+static void design_kfilter(double rate, double pb[3], double pa[2], double ra[2]) {
+  const double pi = 3.14159265358979323846264338327950288;
+  double K = std::tan(pi * 1681.974450955533 / rate);
+  const double Q1 = 0.7071752369554196;
+  const double Vh = std::pow(10.0, 3.999843853973347 / 20.0);
+  const double Vb = std::pow(Vh, 0.4996667741545416);
+  const double d1 = 1.0 + K / Q1 + K * K;
+  pb[0] = (Vh + Vb * K / Q1 + K * K) / d1;
+  pb[1] = 2.0 * (K * K - Vh) / d1;
+  pb[2] = (Vh - Vb * K / Q1 + K * K) / d1;
+  pa[0] = 2.0 * (K * K - 1.0) / d1;
+  pa[1] = (1.0 - K / Q1 + K * K) / d1;
+  K = std::tan(pi * 38.13547087602444 / rate);
+  const double Q2 = 0.5003270373238773;
+  const double d2 = 1.0 + K / Q2 + K * K;
+  ra[0] = 2.0 * (K * K - 1.0) / d2;
+  ra[1] = (1.0 - K / Q2 + K * K) / d2;
+}
+
+typedef long double ld;
+
+static void mat4_mul(const ld *X, const ld *Y, ld *Z) {
+  ld T[16];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      ld s = 0;
+      for (int k = 0; k < 4; ++k) s += X[4 * r + k] * Y[4 * k + c];
+      T[4 * r + c] = s;
+    }
+  memcpy(Z, T, sizeof(T));
+}
+
+// Scan-basis constants.  Chain state (q1, q2, p1, p2) steps as
+//   q0 = w - ra1 q1 - ra2 q2,  p0 = q0 - pa1 p1 - pa2 p2  ->  (q0, q1, p0, p1)
+// i.e. s <- Ac s + Bc w.  With T = [[1,0,0,0],[al,-al*be,0,0],[0,0,ga,0],[0,0,0,ga]]
+// the kernels carry T s; M = T Ac T^-1 is well conditioned (all powers <= ~10),
+// so its powers are formed by plain repeated multiplication in long double.
+static void design_scan_basis(LgdFilt &F, int chunk) {
+  const ld ra1 = F.ra[0], ra2 = F.ra[1], pa1 = F.pa[0], pa2 = F.pa[1];
+  const ld r = sqrtl(ra2);                 // radius of the (nearly double) RLB pole
+  const ld al = 1.0L / (1.0L - r), be = r;
+  const ld dc = 1.0L / (1.0L + pa1 + pa2), ga = 1.0L / dc;
+  F.alpha = (double)al; F.beta = (double)be;
+  F.inv_alpha = (double)(1.0L / al); F.inv_beta = (double)(1.0L / be);
+  F.gamma = (double)ga; F.dc = (double)dc;
+  // use the rounded doubles the kernel will really apply, so T and T^-1 match it
+  const ld alr = F.alpha, ber = F.beta, gar = F.gamma;
+  ld Ac[16] = {-ra1, -ra2, 0, 0, 1, 0, 0, 0, -ra1, -ra2, -pa1, -pa2, 0, 0, 1, 0};
+  ld T[16] = {1, 0, 0, 0, alr, -alr * ber, 0, 0, 0, 0, gar, 0, 0, 0, 0, gar};
+  ld Ti[16] = {1, 0, 0, 0, 1 / ber, -1 / (alr * ber), 0, 0, 0, 0, 1 / gar, 0, 0, 0, 0, 1 / gar};
+  ld M[16], Mk[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  mat4_mul(T, Ac, M);
+  mat4_mul(M, Ti, M);
+  const ld TB[4] = {1, alr, gar, 0};  // T * (1, 0, 1, 0)
+  for (int i = 0; i < chunk; ++i) {
+    if (i == chunk - 2 || i == chunk - 1) {
+      double *g = F.g[i == chunk - 1 ? 0 : 1];  // g[0] = M^(C-1) T Bc, g[1] = M^(C-2) T Bc
+      for (int rr = 0; rr < 4; ++rr) {
+        ld acc = 0;
+        for (int c = 0; c < 4; ++c) acc += Mk[4 * rr + c] * TB[c];
+        g[rr] = (double)acc;
+      }
+    }
+    mat4_mul(M, Mk, Mk);
+  }
+  for (int j = 0; j < 6; ++j) {
+    for (int i = 0; i < 16; ++i) F.P[j][i] = (double)Mk[i];
+    mat4_mul(Mk, Mk, Mk);
+  }
+}
+
+static int interp_factor(unsigned rate) { return rate < 96000 ? 4 : (rate < 192000 ? 2 : 0); }
+
+// 49-tap Hann-windowed sinc split into polyphase branches.
+// Branch 0 is a pure delay (its maximum is the sample peak), so only the
+// non-trivial branches are kept: 3 x 12 taps (4x) or 1 x 24 taps (2x); tap t of
+// a branch multiplies x[n - t].
+static void design_interp(int factor, float tp[36]) {
+  const double pi = 3.14159265358979323846264338327950288;
+  memset(tp, 0, 36 * sizeof(float));
+  if (!factor) return;
+  int count[4] = {0, 0, 0, 0};
+  const int ntap = factor == 4 ? 12 : 24;
+  for (int j = 0; j < 49; ++j) {
+    const double m = (double)j - 24.0;
+    double c = 1.0;
+    if (std::fabs(m) > 0.000001) c = std::sin(m * pi / factor) / (m * pi / factor);
+    c *= 0.5 * (1.0 - std::cos(2.0 * pi * j / 48.0));
+    if (std::fabs(c) > 0.000001) {
+      const int f = j % factor, t = count[f]++;
+      if (f > 0 && t < ntap) tp[(f - 1) * ntap + t] = (float)c;  // index j / factor == t
+    }
+  }
+}
+
+// ------------------------------------------------------------------ context --
+struct Group {  // tracks sharing (rate, channels) -> one scan launch
+  unsigned rate, nch;
+  int chunk, tp;
+  LgdFilt F;
+  size_t seg_begin, seg_count;
+};
+
+struct lgd_ctx {
+  int device = 0;
+  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 3, p_waves_per_cu = 8;
+  int n_cu = 256;
+  // plan
+  bool planned = false, executed = false;
+  uint32_t flags = 0;
+  std::vector<lgd_track> tracks;
+  std::vector<LgdTrackMeta> meta;
+  std::vector<LgdSeg> segs;
+  std::vector<LgdRange> ranges;
+  std::vector<Group> groups;
+  uint64_t total_sb = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0, warm_bytes = 0;
+  // device workspace
+  double *d_E = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
+  double *d_part1 = nullptr, *d_part2 = nullptr;
+  float *d_peaks = nullptr;
+  LgdTrackMeta *d_meta = nullptr;
+  LgdSeg *d_segs = nullptr;
+  LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
+  LgdRange *h_album_range = nullptr;  // pinned
+  size_t cap_E = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_meta = 0, cap_segs = 0,
+         cap_ranges = 0;
+  hipStream_t last_stream = nullptr;
+  // ring of (start, scan kernel done, all done) event triples, one per execute
+  static const int EV_RING = 64;
+  hipEvent_t ev[EV_RING][3];
+  uint64_t n_exec = 0;
+  double abs_gate, rel_factor, minus20;
+};
+
+template <typename T>
+static int ensure(T **p, size_t *cap, size_t need) {
+  if (need <= *cap && *p) return LGD_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  size_t n = need ? need : 1;
+  HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+  *cap = n;
+  return LGD_OK;
+}
+
+extern "C" const char *lgd_last_error(void) { return g_err.c_str(); }
+
+extern "C" lgd_ctx *lgd_create(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+    fail(LGD_EHIP, "no HIP device %d (count %d): the scanner has no CPU fallback", device, n);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    fail(LGD_EHIP, "hipSetDevice(%d) failed", device);
+    return nullptr;
+  }
+  lgd_ctx *c = new lgd_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  c->abs_gate = std::pow(10.0, (-70.0 + 0.691) / 10.0);
+  c->rel_factor = std::pow(10.0, -10.0 / 10.0);
+  c->minus20 = std::pow(10.0, -20.0 / 10.0);
+  bool ok = true;
+  memset(c->ev, 0, sizeof(c->ev));
+  for (int i = 0; i < lgd_ctx::EV_RING; ++i)
+    for (int j = 0; j < 3; ++j) ok = ok && hipEventCreate(&c->ev[i][j]) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->d_album, 16 * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->d_part1, 4 * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->d_part2, 2 * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->d_album_range, sizeof(LgdRange)) == hipSuccess;
+  ok = ok && hipHostMalloc((void **)&c->h_album_range, sizeof(LgdRange)) == hipSuccess;
+  if (!ok) {
+    fail(LGD_ENOMEM, "lgd_create: allocation failed");
+    lgd_destroy(c);
+    return nullptr;
+  }
+  return c;
+}
+
+extern "C" void lgd_destroy(lgd_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  void *ptrs[] = {c->d_E, c->d_st, c->d_res, c->d_album, c->d_part1, c->d_part2, c->d_peaks,
+                  c->d_meta, c->d_segs, c->d_ranges, c->d_album_range};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (c->h_album_range) (void)hipHostFree(c->h_album_range);
+  for (int i = 0; i < lgd_ctx::EV_RING; ++i)
+    for (int j = 0; j < 3; ++j)
+      if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+  delete c;
+}
+
+extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
+  if (!c || !name) return fail(LGD_EINVAL, "lgd_set_param: null argument");
+  if (value < 0) return fail(LGD_EINVAL, "lgd_set_param(%s): negative value", name);
+  if (!strcmp(name, "chunk")) c->p_chunk = value;
+  else if (!strcmp(name, "seg_subblocks")) c->p_seg_sb = value;
+  else if (!strcmp(name, "warm_subblocks")) c->p_warm_sb = value;
+  else if (!strcmp(name, "waves_per_cu")) c->p_waves_per_cu = value ? value : 8;
+  else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
+  c->planned = false;
+  return LGD_OK;
+}
+
+static int pick_chunk(long forced, int s100, unsigned nch) {
+  if (forced) {
+    for (const int *p = lgd_chunk_table; *p; ++p)
+      if (*p == forced && s100 % *p == 0) return *p;
+    return 0;
+  }
+  // preference: amortise the wave scan (large C) within the LDS/VGPR budget
+  static const int pref[] = {50, 49, 45, 35, 63, 25, 75, 0};
+  (void)nch;
+  for (const int *p = pref; *p; ++p)
+    if (s100 % *p == 0) return *p;
+  return 0;
+}
+
+extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_t flags) {
+  if (!c) return fail(LGD_EINVAL, "lgd_plan: null context");
+  if (n && !tracks) return fail(LGD_EINVAL, "lgd_plan: null track array");
+  HIPCHK(hipSetDevice(c->device));
+  c->planned = c->executed = false;
+  c->flags = flags;
+  c->tracks.assign(tracks, tracks + n);
+  c->meta.assign(n, LgdTrackMeta());
+  c->segs.clear();
+  c->ranges.clear();
+  c->groups.clear();
+  c->total_sb = c->total_st = c->total_peak_floats = c->pcm_bytes = c->warm_bytes = 0;
+
+  for (uint32_t t = 0; t < n; ++t) {
+    const lgd_track &tr = tracks[t];
+    // ebur128_init's own argument checks
+    if (tr.channels == 0 || tr.channels > LGD_MAX_CHANNELS)
+      return fail(LGD_EINVAL, "track %u: %u channels (1..64 supported)", t, tr.channels);
+    if (tr.rate < 16 || tr.rate > 2822400)
+      return fail(LGD_EINVAL, "track %u: sample rate %u out of range", t, tr.rate);
+    if (tr.frames && !tr.pcm) return fail(LGD_EINVAL, "track %u: null PCM pointer", t);
+    if (((uintptr_t)tr.pcm) & 15)
+      return fail(LGD_EINVAL, "track %u: PCM pointer must be 16-byte aligned", t);
+    if (tr.channels > 2)
+      return fail(LGD_EUNSUP, "track %u: %u channels not covered by the kernels yet", t,
+                  tr.channels);
+    LgdTrackMeta &m = c->meta[t];
+    m.s100 = (int)((tr.rate + 5) / 10);
+    m.nch = (int)tr.channels;
+    const uint64_t nsb = tr.frames / (uint64_t)m.s100;
+    if (nsb > 0x7fffffffull) return fail(LGD_EUNSUP, "track %u too long", t);
+    m.n_sb = (int)nsb;
+    m.n_st_slots = m.n_sb >= 30 ? (m.n_sb - 30) / 10 + 1 : 0;
+    m.sb_off = (long long)c->total_sb;
+    m.st_off = (long long)c->total_st;
+    c->total_sb += nsb;
+    c->total_st += (uint64_t)m.n_st_slots;
+    c->pcm_bytes += tr.frames * tr.channels * 4ull;
+  }
+
+  // group tracks by (rate, channels)
+  std::map<std::pair<unsigned, unsigned>, std::vector<uint32_t>> by_cfg;
+  for (uint32_t t = 0; t < n; ++t) by_cfg[{tracks[t].rate, tracks[t].channels}].push_back(t);
+
+  // segment length: spread all sub-blocks over ~waves_per_cu waves per CU
+  const uint64_t target_waves = (uint64_t)c->n_cu * (uint64_t)c->p_waves_per_cu;
+  uint64_t seg_sb = c->p_seg_sb ? (uint64_t)c->p_seg_sb
+                                : (c->total_sb + target_waves - 1) / (target_waves ? target_waves : 1);
+  const uint64_t min_seg = (uint64_t)std::max<long>(4, 3 * c->p_warm_sb);
+  if (!c->p_seg_sb && seg_sb < min_seg) seg_sb = min_seg;  // keep the warm-up overhead bounded
+  if (seg_sb < 1) seg_sb = 1;
+
+  for (auto &kv : by_cfg) {
+    Group g;
+    g.rate = kv.first.first;
+    g.nch = kv.first.second;
+    const int s100 = (int)((g.rate + 5) / 10);
+    g.chunk = pick_chunk(c->p_chunk, s100, g.nch);
+    if (!g.chunk)
+      return fail(LGD_EUNSUP, "no compiled chunk length divides the %d-frame sub-block of %u Hz",
+                  s100, g.rate);
+    g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
+    memset(&g.F, 0, sizeof(g.F));
+    design_kfilter((double)g.rate, g.F.pb, g.F.pa, g.F.ra);
+    design_scan_basis(g.F, g.chunk);
+    design_interp(g.tp, g.F.tp);
+    g.F.w[0] = g.F.w[1] = 1.0f;  // L, R (mono is NOT dual-mono: weight 1.0)
+    g.F.lps = s100 / g.chunk;
+    g.seg_begin = c->segs.size();
+    const long long tile_f = 64LL * g.chunk;
+    const int warm_tiles =
+        c->p_warm_sb ? (int)(((long long)c->p_warm_sb * s100 + tile_f - 1) / tile_f) : 0;
+    for (uint32_t t : kv.second) {
+      const lgd_track &tr = tracks[t];
+      LgdTrackMeta &m = c->meta[t];
+      const uint64_t nsb = (uint64_t)m.n_sb;
+      uint64_t nseg = nsb ? (nsb + seg_sb - 1) / seg_sb : 1;
+      m.n_seg = (int)nseg;
+      m.peak_off = (long long)c->total_peak_floats;
+      c->total_peak_floats += nseg * 2ull * tr.channels;
+      uint64_t sb0 = 0;
+      for (uint64_t s = 0; s < nseg; ++s) {
+        const uint64_t cnt = nsb / nseg + (s < nsb % nseg ? 1 : 0);
+        LgdSeg sg;
+        sg.pcm = tr.pcm;
+        sg.n_floats = (long long)(tr.frames * tr.channels);
+        sg.f0 = (long long)(sb0 * (uint64_t)s100);
+        sg.n_sb = (int)cnt;
+        sg.f_peak_end = (s + 1 == nseg) ? (long long)tr.frames : (long long)((sb0 + cnt) * s100);
+        sg.n_warm_tiles = sb0 ? warm_tiles : 0;
+        // offsets are patched to pointers once the workspace exists
+        sg.e_out = (double *)(uintptr_t)(m.sb_off + (long long)sb0);
+        sg.peak_out = (float *)(uintptr_t)(m.peak_off + (long long)(s * 2ull * tr.channels));
+        c->segs.push_back(sg);
+        if (sb0) c->warm_bytes += (uint64_t)warm_tiles * tile_f * tr.channels * 4ull;
+        sb0 += cnt;
+      }
+    }
+    g.seg_count = c->segs.size() - g.seg_begin;
+    c->groups.push_back(g);
+  }
+
+  int rc;
+  if ((rc = ensure(&c->d_E, &c->cap_E, c->total_sb))) return rc;
+  if ((rc = ensure(&c->d_st, &c->cap_st, c->total_st))) return rc;
+  if ((rc = ensure(&c->d_res, &c->cap_res, (size_t)n * LGR_STRIDE))) return rc;
+  if ((rc = ensure(&c->d_peaks, &c->cap_peaks, c->total_peak_floats))) return rc;
+  if ((rc = ensure(&c->d_meta, &c->cap_meta, n))) return rc;
+  if ((rc = ensure(&c->d_segs, &c->cap_segs, c->segs.size()))) return rc;
+  if ((rc = ensure(&c->d_ranges, &c->cap_ranges, n))) return rc;
+
+  for (LgdSeg &sg : c->segs) {
+    sg.e_out = c->d_E + (uintptr_t)sg.e_out;
+    sg.peak_out = c->d_peaks + (uintptr_t)sg.peak_out;
+  }
+  c->ranges.resize(n);
+  for (uint32_t t = 0; t < n; ++t) {
+    c->ranges[t].off = c->meta[t].st_off;
+    c->ranges[t].n = c->meta[t].n_st_slots;
+    c->ranges[t].out = c->d_res + (size_t)t * LGR_STRIDE + LGR_LRA;
+  }
+  if (n) {
+    HIPCHK(hipMemcpy(c->d_meta, c->meta.data(), n * sizeof(LgdTrackMeta), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_ranges, c->ranges.data(), n * sizeof(LgdRange), hipMemcpyHostToDevice));
+  }
+  if (!c->segs.empty())
+    HIPCHK(hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(LgdSeg),
+                     hipMemcpyHostToDevice));
+  c->planned = true;
+  return LGD_OK;
+}
+
+extern "C" int lgd_album_stage2(lgd_ctx *c, void *hip_stream) {
+  if (!c || !c->planned || !c->executed) return fail(LGD_ESTATE, "album stage 2 before execute");
+  hipStream_t s = (hipStream_t)hip_stream;
+  HIPCHK(lgd_launch_album_stage2(c->d_meta, (int)c->tracks.size(), c->d_E, c->d_res, c->d_part1,
+                                 c->d_part2, c->abs_gate, c->rel_factor, s));
+  return LGD_OK;
+}
+
+extern "C" int lgd_album_stage3(lgd_ctx *c, const double *st_all, uint64_t n_slots,
+                                void *hip_stream) {
+  if (!c || !c->planned || !c->executed) return fail(LGD_ESTATE, "album stage 3 before execute");
+  hipStream_t s = (hipStream_t)hip_stream;
+  HIPCHK(lgd_launch_album_final(c->d_part1, c->d_part2, c->rel_factor, c->d_album, s));
+  c->h_album_range->off = 0;
+  c->h_album_range->n = st_all ? (long long)n_slots : (long long)c->total_st;
+  c->h_album_range->out = c->d_album + 1;
+  HIPCHK(hipMemcpyAsync(c->d_album_range, c->h_album_range, sizeof(LgdRange),
+                        hipMemcpyHostToDevice, s));
+  HIPCHK(lgd_launch_lra(c->d_album_range, 1, st_all ? st_all : c->d_st, c->minus20, s));
+  return LGD_OK;
+}
+
+extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
+  if (!c || !c->planned) return fail(LGD_ESTATE, "lgd_execute before lgd_plan");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int n = (int)c->tracks.size();
+  c->last_stream = s;
+  hipEvent_t *ev = c->ev[c->n_exec % lgd_ctx::EV_RING];
+  HIPCHK(hipEventRecord(ev[0], s));
+  for (const Group &g : c->groups)
+    HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, c->d_segs + g.seg_begin, (int)g.seg_count,
+                           &g.F, s));
+  HIPCHK(hipEventRecord(ev[1], s));
+  HIPCHK(lgd_launch_track_epilogue(c->d_meta, n, c->d_E, c->d_st, c->d_peaks, c->d_res,
+                                   c->abs_gate, c->rel_factor,
+                                   (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
+  HIPCHK(lgd_launch_lra(c->d_ranges, n, c->d_st, c->minus20, s));
+  c->executed = true;
+  if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))
+    HIPCHK(lgd_launch_album_part1(c->d_res, n, c->d_part1, s));
+  if (c->flags & LGD_FLAG_ALBUM) {
+    int rc;
+    if ((rc = lgd_album_stage2(c, hip_stream))) return rc;
+    if ((rc = lgd_album_stage3(c, nullptr, 0, hip_stream))) return rc;
+  }
+  HIPCHK(hipEventRecord(ev[2], s));
+  ++c->n_exec;
+  return LGD_OK;
+}
+
+extern "C" int lgd_fetch(lgd_ctx *c, lgd_track_result *out, lgd_album_result *album) {
+  if (!c || !c->executed) return fail(LGD_ESTATE, "lgd_fetch before lgd_execute");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->last_stream));
+  const size_t n = c->tracks.size();
+  if (n && out) {
+    std::vector<double> r(n * LGR_STRIDE);
+    HIPCHK(hipMemcpy(r.data(), c->d_res, r.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t t = 0; t < n; ++t) {
+      const double *p = &r[t * LGR_STRIDE];
+      lgd_track_result &o = out[t];
+      o.loudness = p[LGR_LOUDNESS];
+      o.lra = p[LGR_LRA];
+      o.peak = p[LGR_PEAK];
+      o.sample_peak = p[LGR_SPEAK];
+      o.true_peak = p[LGR_TPEAK];
+      o.rel_threshold = p[LGR_THR];
+      o.sum_abs = p[LGR_SUM_ABS];
+      o.sum_rel = p[LGR_SUM_REL];
+      o.n_blocks = (uint64_t)p[LGR_NBLK];
+      o.n_abs = (uint64_t)p[LGR_NABS];
+      o.n_rel = (uint64_t)p[LGR_NREL];
+      o.n_st_blocks = (uint64_t)p[LGR_NSTBLK];
+      o.n_st = (uint64_t)p[LGR_NST];
+    }
+  }
+  if (album) {
+    if (!(c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1)))
+      return fail(LGD_ESTATE, "plan was made without an album flag");
+    double a[9];
+    HIPCHK(hipMemcpy(a, c->d_album, sizeof(a), hipMemcpyDeviceToHost));
+    album->loudness = a[0];
+    album->lra = a[1];
+    album->peak = a[2];
+    album->rel_threshold = a[3];
+    album->sum_abs = a[4];
+    album->sum_rel = a[5];
+    album->n_abs = (uint64_t)a[6];
+    album->n_rel = (uint64_t)a[7];
+    album->n_st = (uint64_t)a[8];
+  }
+  return LGD_OK;
+}
+
+extern "C" int lgd_album_part1_ptr(lgd_ctx *c, lgd_album_part1 **p) {
+  if (!c || !p) return fail(LGD_EINVAL, "null argument");
+  *p = (lgd_album_part1 *)c->d_part1;
+  return LGD_OK;
+}
+extern "C" int lgd_album_part2_ptr(lgd_ctx *c, lgd_album_part2 **p) {
+  if (!c || !p) return fail(LGD_EINVAL, "null argument");
+  *p = (lgd_album_part2 *)c->d_part2;
+  return LGD_OK;
+}
+extern "C" int lgd_album_st_ptr(lgd_ctx *c, double **p, uint64_t *n_slots) {
+  if (!c || !p || !n_slots) return fail(LGD_EINVAL, "null argument");
+  if (!c->planned) return fail(LGD_ESTATE, "no plan");
+  *p = c->d_st;
+  *n_slots = c->total_st;
+  return LGD_OK;
+}
+
+extern "C" int lgd_copy_subblock_energies(lgd_ctx *c, uint32_t track, double *host_out,
+                                          uint64_t cap, uint64_t *n_out) {
+  if (!c || !c->executed) return fail(LGD_ESTATE, "no executed plan");
+  if (track >= c->tracks.size()) return fail(LGD_EINVAL, "track index too high");
+  HIPCHK(hipStreamSynchronize(c->last_stream));
+  const LgdTrackMeta &m = c->meta[track];
+  const uint64_t n = std::min<uint64_t>(cap, (uint64_t)m.n_sb);
+  if (n_out) *n_out = (uint64_t)m.n_sb;
+  if (n && host_out)
+    HIPCHK(hipMemcpy(host_out, c->d_E + m.sb_off, n * sizeof(double), hipMemcpyDeviceToHost));
+  return LGD_OK;
+}
+
+extern "C" int lgd_last_kernel_ms(lgd_ctx *c, float *scan_ms, float *total_ms) {
+  if (!c || !c->n_exec) return fail(LGD_ESTATE, "no executed plan");
+  hipEvent_t *ev = c->ev[(c->n_exec - 1) % lgd_ctx::EV_RING];
+  HIPCHK(hipEventSynchronize(ev[2]));
+  if (scan_ms) HIPCHK(hipEventElapsedTime(scan_ms, ev[0], ev[1]));
+  if (total_ms) HIPCHK(hipEventElapsedTime(total_ms, ev[0], ev[2]));
+  return LGD_OK;
+}
+
+extern "C" int lgd_kernel_ms_stats(lgd_ctx *c, uint32_t last_n, float *scan_mean, float *scan_min,
+                                   float *total_mean, uint32_t *n_used) {
+  if (!c || !c->n_exec) return fail(LGD_ESTATE, "no executed plan");
+  uint64_t n = std::min<uint64_t>(std::min<uint64_t>(last_n ? last_n : lgd_ctx::EV_RING,
+                                                     lgd_ctx::EV_RING), c->n_exec);
+  double sa = 0, ta = 0;
+  float smin = 1e30f;
+  for (uint64_t i = 0; i < n; ++i) {
+    hipEvent_t *ev = c->ev[(c->n_exec - 1 - i) % lgd_ctx::EV_RING];
+    float a = 0, b = 0;
+    HIPCHK(hipEventSynchronize(ev[2]));
+    HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, ev[0], ev[2]));
+    sa += a; ta += b;
+    smin = std::min(smin, a);
+  }
+  if (scan_mean) *scan_mean = (float)(sa / (double)n);
+  if (scan_min) *scan_min = smin;
+  if (total_mean) *total_mean = (float)(ta / (double)n);
+  if (n_used) *n_used = (uint32_t)n;
+  return LGD_OK;
+}
+
+extern "C" int lgd_plan_info(lgd_ctx *c, uint64_t *n_segments, uint64_t *n_subblocks,
+                             uint32_t *chunk, uint64_t *pcm_bytes, uint64_t *warm_bytes) {
+  if (!c || !c->planned) return fail(LGD_ESTATE, "no plan");
+  if (n_segments) *n_segments = c->segs.size();
+  if (n_subblocks) *n_subblocks = c->total_sb;
+  if (chunk) *chunk = c->groups.empty() ? 0u : (uint32_t)c->groups[0].chunk;
+  if (pcm_bytes) *pcm_bytes = c->pcm_bytes;
+  if (warm_bytes) *warm_bytes = c->warm_bytes;
+  return LGD_OK;
+}

@@ -1,0 +1,62 @@
+// lgd_internal.h -- structures shared by the host engine and the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+// One unit of work for one wavefront: a run of whole 100 ms sub-blocks of one
+// track (plus, for the last segment of a track, the trailing partial sub-block,
+// which only feeds the peaks -- SURVEY.md A.3: leftover frames are filtered
+// but never form a block).
+struct LgdSeg {
+  const float *pcm;      // track base (interleaved f32, 16-B aligned)
+  long long n_floats;    // frames * channels of the whole track
+  long long f0;          // first frame of this segment (multiple of s100)
+  long long f_peak_end;  // tiles cover [f0, f_peak_end)
+  double *e_out;         // sub-block energies of this segment, n_sb slots
+  float *peak_out;       // [2][nch]: sample peaks, then interpolated peaks
+  int n_sb;              // whole sub-blocks in this segment
+  int n_warm_tiles;      // K-filter warm-up tiles run before f0 (0 at track start)
+};
+
+// Per-(rate, chunk) constants, passed by value as a kernel argument.
+// Filter chain: y = pb(z) / pa(z) * (1 - z^-1)^2 / ra(z) x.
+// Scan basis: s = (q1, alpha (q1 - beta q2), gamma p1, gamma p2), gamma = 1/dc.
+struct LgdFilt {
+  double ra[2];      // RLB denominator a1, a2
+  double pa[2];      // shelf denominator a1, a2
+  double pb[3];      // shelf numerator
+  double alpha, beta, inv_alpha, inv_beta;  // slope coordinate of the RLB pole pair
+  double gamma, dc;  // shelf-state scaling (dc = 1 / (1 + pa1 + pa2))
+  double g[2][4];    // effect of w[0], w[1] of a chunk on its end state (scan basis)
+  double P[6][16];   // transition over C * 2^j frames, j = 0..5 (scan basis, row-major;
+                     // block lower triangular: P[.][2], [3], [6], [7] are zero)
+  float tp[36];      // 4x: phases 1..3 x 12 taps; 2x: phase 1 x 24 taps (A.5)
+  float w[2];        // channel weights of the 1/2-channel fast path
+  int lps;           // lanes (C-frame chunks) per 100 ms sub-block = s100 / C
+  int pad;
+};
+
+struct LgdTrackMeta {
+  long long sb_off;   // first slot of this track in the sub-block energy array
+  long long st_off;   // first slot in the short-term energy array
+  long long peak_off; // first float of this track's [n_seg][2][nch] peak partials
+  int n_sb;           // whole sub-blocks
+  int n_st_slots;     // short-term blocks evaluated: n_sb >= 30 ? (n_sb-30)/10+1 : 0
+  int n_seg;
+  int s100;
+  int nch;
+  int pad;
+};
+
+// one loudness-range problem: listed short-term energies st[off, off+n) -> *out
+struct LgdRange {
+  long long off;
+  long long n;
+  double *out;
+};
+
+// per-track device result: 16 doubles (counts are integer-valued doubles)
+enum {
+  LGR_LOUDNESS = 0, LGR_LRA, LGR_PEAK, LGR_SPEAK, LGR_TPEAK, LGR_THR, LGR_SUM_ABS,
+  LGR_SUM_REL, LGR_NBLK, LGR_NABS, LGR_NREL, LGR_NSTBLK, LGR_NST, LGR_ALB_SUM_REL,
+  LGR_ALB_NREL, LGR_SPARE, LGR_STRIDE
+};

@@ -1,0 +1,139 @@
+"""ctypes binding of the device-level C ABI (include/loudscan_device.h).
+
+PyTorch is plumbing only here: it owns the HBM buffers and the HIP stream that
+the C ABI is handed as plain pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (FLAG_ALBUM, FLAG_ALBUM_PART1, FLAG_TRUE_PEAK, LgdAlbumResult, LgdTrack,
+                   LgdTrackResult)
+
+
+class LoudscanError(RuntimeError):
+    pass
+
+
+def _stream_handle(stream):
+    if stream is None:
+        return None
+    if isinstance(stream, int):
+        return stream
+    return stream.cuda_stream  # torch.cuda.Stream
+
+
+class DeviceScanner:
+    """One lgd_ctx: plan -> execute (async) -> fetch."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        self.ctx = self.L.lgd_create(int(device))
+        if not self.ctx:
+            raise LoudscanError(self.L.lgd_last_error().decode())
+        self.device = int(device)
+        self._keep = None
+        self.n_tracks = 0
+        self.flags = 0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.lgd_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LoudscanError("%s (code %d)" % (self.L.lgd_last_error().decode(), rc))
+
+    def set_param(self, name, value):
+        self._chk(self.L.lgd_set_param(self.ctx, name.encode(), int(value)))
+
+    def plan(self, tracks, rates, true_peak=True, album=False):
+        """tracks: device torch tensors [frames, channels] float32 contiguous, or
+        (ptr, frames, channels) tuples; rates: int or list of ints."""
+        if isinstance(rates, int):
+            rates = [rates] * len(tracks)
+        arr = (LgdTrack * max(1, len(tracks)))()
+        for i, (t, r) in enumerate(zip(tracks, rates)):
+            if isinstance(t, tuple):
+                ptr, frames, ch = t
+            else:
+                if t.dim() != 2 or not t.is_contiguous() or t.dtype.is_floating_point is False \
+                        or t.element_size() != 4:
+                    raise LoudscanError("track %d: need a contiguous [frames, channels] float32 tensor" % i)
+                if not t.is_cuda:
+                    raise LoudscanError("track %d: PCM must be resident in HBM (device tensor)" % i)
+                ptr, frames, ch = t.data_ptr(), t.shape[0], t.shape[1]
+            arr[i] = LgdTrack(ptr, frames, ch, int(r))
+        self._keep = tracks
+        self.n_tracks = len(tracks)
+        # album: False | True (all stages on this GPU) | "part1" (multi-GPU: the
+        # caller exchanges the partials and drives stages 2 and 3)
+        aflag = FLAG_ALBUM_PART1 if album == "part1" else (FLAG_ALBUM if album else 0)
+        self.flags = (FLAG_TRUE_PEAK if true_peak else 0) | aflag
+        self._chk(self.L.lgd_plan(self.ctx, arr, len(tracks), self.flags))
+        return self
+
+    def execute(self, stream=None):
+        self._chk(self.L.lgd_execute(self.ctx, _stream_handle(stream)))
+        return self
+
+    def fetch(self):
+        res = (LgdTrackResult * max(1, self.n_tracks))()
+        alb = LgdAlbumResult()
+        want_album = bool(self.flags & (FLAG_ALBUM | FLAG_ALBUM_PART1))
+        self._chk(self.L.lgd_fetch(self.ctx, res, C.byref(alb) if want_album else None))
+        tracks = [res[i].asdict() for i in range(self.n_tracks)]
+        return tracks, (alb.asdict() if want_album else None)
+
+    def scan(self, tracks, rates, true_peak=True, album=False, stream=None):
+        return self.plan(tracks, rates, true_peak, album).execute(stream).fetch()
+
+    # -- introspection -----------------------------------------------------------
+    def subblock_energies(self, track):
+        n = C.c_uint64()
+        self._chk(self.L.lgd_copy_subblock_energies(self.ctx, track, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float64)
+        if n.value:
+            self._chk(self.L.lgd_copy_subblock_energies(self.ctx, track, out.ctypes.data, n.value,
+                                                        C.byref(n)))
+        return out
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(-1), C.c_float(-1)
+        self._chk(self.L.lgd_last_kernel_ms(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def kernel_ms_stats(self, last_n=0):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        n = C.c_uint32()
+        self._chk(self.L.lgd_kernel_ms_stats(self.ctx, last_n, C.byref(a), C.byref(b), C.byref(c),
+                                             C.byref(n)))
+        return dict(scan_mean_ms=a.value, scan_min_ms=b.value, total_mean_ms=c.value, n=n.value)
+
+    def plan_info(self):
+        ns, nb, pb, wb = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ck = C.c_uint32()
+        self._chk(self.L.lgd_plan_info(self.ctx, C.byref(ns), C.byref(nb), C.byref(ck),
+                                       C.byref(pb), C.byref(wb)))
+        return dict(segments=ns.value, subblocks=nb.value, chunk=ck.value, pcm_bytes=pb.value,
+                    warm_bytes=wb.value)
+
+    # -- multi-GPU album plumbing (device pointers of the partials) -----------------
+    def album_part_ptrs(self):
+        p1, p2, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = C.c_uint64()
+        self._chk(self.L.lgd_album_part1_ptr(self.ctx, C.byref(p1)))
+        self._chk(self.L.lgd_album_part2_ptr(self.ctx, C.byref(p2)))
+        self._chk(self.L.lgd_album_st_ptr(self.ctx, C.byref(st), C.byref(n)))
+        return p1.value, p2.value, st.value, n.value
+
+    def album_stage2(self, stream=None):
+        self._chk(self.L.lgd_album_stage2(self.ctx, _stream_handle(stream)))
+
+    def album_stage3(self, st_all_ptr=None, n_slots=0, stream=None):
+        self._chk(self.L.lgd_album_stage3(self.ctx, st_all_ptr, n_slots, _stream_handle(stream)))

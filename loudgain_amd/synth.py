@@ -1,0 +1,52 @@
+"""Synthetic programme material of the benchmark.
+
+Gaussian noise at -20 dBFS RMS whose level steps through
+{0, -6, -12, -30, -50, -80} dB every `step_s` seconds (exercises the absolute
+gate, the relative gate and the loudness range), plus a 1 s fs/4 sine at 45
+degrees phase and 0.9 FS at t = 5 s (inter-sample peak above the sample peak);
+every value snapped to the S16 grid k/32768 so that the reference's S16 feed
+(scan.c:414) and the f32 path see identical numbers.
+"""
+import numpy as np
+
+STEPS_DB = (0.0, -6.0, -12.0, -30.0, -50.0, -80.0)
+
+
+def track_numpy(frames, channels, rate, seed=0, step_s=10.0):
+    rng = np.random.Generator(np.random.Philox(key=0x10AD6A1 ^ int(seed)))
+    x = rng.standard_normal((frames, channels), dtype=np.float32) * np.float32(0.1)
+    gains = (10.0 ** (np.array(STEPS_DB) / 20.0)).astype(np.float32)
+    seg = (np.arange(frames) // int(step_s * rate)) % len(STEPS_DB)
+    x *= gains[seg][:, None]
+    t0, t1 = int(5 * rate), min(frames, int(6 * rate))
+    if t1 > t0:
+        n = np.arange(t1 - t0)
+        x[t0:t1] += (0.9 * np.sin(2 * np.pi * n / 4.0 + np.pi / 4)).astype(np.float32)[:, None]
+    return snap_s16_numpy(x)
+
+
+def snap_s16_numpy(x):
+    return (np.clip(np.round(x.astype(np.float64) * 32768.0), -32768, 32767) / 32768.0).astype(np.float32)
+
+
+def track_torch(frames, channels, rate, seed=0, step_s=10.0, device="cuda"):
+    """Same construction generated directly in HBM (torch's Philox stream; not
+    bit-identical to track_numpy -- copy it back to the host to feed the oracle)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(0x10AD6A1 ^ int(seed))
+    x = torch.empty((frames, channels), dtype=torch.float32, device=device)
+    piece = 1 << 24
+    gains = torch.tensor([10.0 ** (d / 20.0) for d in STEPS_DB], dtype=torch.float32, device=device)
+    for off in range(0, frames, piece):
+        n = min(piece, frames - off)
+        blk = torch.randn((n, channels), generator=g, dtype=torch.float32, device=device) * 0.1
+        idx = (torch.arange(off, off + n, device=device) // int(step_s * rate)) % len(STEPS_DB)
+        blk *= gains[idx][:, None]
+        x[off:off + n] = blk
+    t0, t1 = int(5 * rate), min(frames, int(6 * rate))
+    if t1 > t0:
+        n = torch.arange(t1 - t0, device=device, dtype=torch.float32)
+        x[t0:t1] += (0.9 * torch.sin(2 * np.pi * n / 4.0 + np.pi / 4))[:, None]
+    x.mul_(32768.0).round_().clamp_(-32768, 32767).div_(32768.0)
+    return x

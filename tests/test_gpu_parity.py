@@ -1,0 +1,167 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle, same inputs.
+
+Bars (BASELINE.json north_star): integer block counts bit-exact; loudness and
+LRA within +-0.01 LU; true peak within +-0.0001.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from loudgain_amd import synth
+from tests.gpu_util import (ENERGY_RTOL, check_track, energy_rtol, gating_blocks_from_subblocks,
+                            to_dev)
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tracks.json")))
+ABS_GATE = 10 ** ((-70 + 0.691) / 10)
+
+
+@pytest.fixture(scope="module")
+def scanner():
+    from loudgain_amd.device import DeviceScanner
+    s = DeviceScanner(0)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("g", GOLD, ids=[g["name"] for g in GOLD])
+def test_golden_and_oracle(scanner, oracle, g):
+    pcm = synth.track_numpy(g["frames"], g["channels"], g["rate"], seed=g["seed"], step_s=g["step_s"])
+    ref = oracle.scan_track(pcm, g["rate"])
+    (got,), _ = scanner.scan([to_dev(pcm)], g["rate"])
+    check_track(got, ref, rate=g["rate"])
+    # committed golden vector
+    assert (got["n_abs"], got["n_rel"], got["n_st"]) == (g["n_abs"], g["n_rel"], g["n_st"])
+    if g["loudness"] != "-inf":
+        assert abs(got["loudness"] - g["loudness"]) <= 1e-6
+    assert abs(got["lra"] - g["lra"]) <= 1e-6
+    assert abs(got["peak"] - g["peak"]) <= 1e-4
+    # block energies one by one
+    s100 = (g["rate"] + 5) // 10
+    z = gating_blocks_from_subblocks(scanner.subblock_energies(0), s100)
+    listed = z[z >= ABS_GATE]
+    refb = ref["state"].gating_blocks()
+    assert len(listed) == len(refb)
+    np.testing.assert_allclose(listed, refb, rtol=energy_rtol(g["rate"]))
+
+
+@pytest.mark.parametrize("frames", [0, 1, 11, 12, 13, 4799, 4800, 19199, 19200, 19201, 24000,
+                                    143999, 144000, 144001, 1600 * 64 + 5])
+def test_ragged_lengths(scanner, oracle, frames):
+    pcm = synth.track_numpy(max(frames, 1), 2, 48000, seed=frames, step_s=0.7)[:frames]
+    pcm = np.ascontiguousarray(pcm)
+    ref = oracle.scan_track(pcm, 48000)
+    import torch
+    dev = to_dev(pcm) if frames else torch.zeros((0, 2), dtype=torch.float32, device="cuda")
+    (got,), _ = scanner.scan([dev], 48000)
+    check_track(got, ref)
+
+
+def test_silence_and_full_scale(scanner, oracle):
+    sil = np.zeros((48000 * 5, 2), np.float32)
+    (got,), _ = scanner.scan([to_dev(sil)], 48000)
+    assert got["loudness"] == -math.inf and got["lra"] == 0.0 and got["peak"] == 0.0
+    assert got["n_abs"] == 0 and got["n_blocks"] == 47
+    fs = np.full((48000 * 4, 1), -1.0, np.float32)
+    fs[::2] = 32767 / 32768
+    ref = oracle.scan_track(fs, 48000)
+    (got,), _ = scanner.scan([to_dev(fs)], 48000)
+    check_track(got, ref)
+    assert got["sample_peak"] == 1.0
+
+
+def test_true_peak_switch(scanner, oracle):
+    pcm = synth.track_numpy(48000 * 8, 2, 48000, seed=5)
+    ref = oracle.scan_track(pcm, 48000)
+    (got,), _ = scanner.scan([to_dev(pcm)], 48000, true_peak=False)
+    check_track(got, ref, tp=False)
+    assert got["true_peak"] == 0.0 and got["peak"] == got["sample_peak"]
+
+
+@pytest.mark.parametrize("seg,warm,chunk", [(1, 2, 0), (3, 2, 25), (7, 3, 50), (1000000, 2, 75),
+                                            (5, 2, 0)])
+def test_segmentation_invariance(oracle, seg, warm, chunk):
+    """Results must not depend on how the track is cut into wave segments."""
+    from loudgain_amd.device import DeviceScanner
+    pcm = synth.track_numpy(48000 * 47 + 321, 2, 48000, seed=77, step_s=3.0)
+    ref = oracle.scan_track(pcm, 48000)
+    s = DeviceScanner(0)
+    s.set_param("seg_subblocks", seg)
+    s.set_param("warm_subblocks", warm)
+    s.set_param("chunk", chunk)
+    (got,), _ = s.scan([to_dev(pcm)], 48000)
+    check_track(got, ref)
+    z = gating_blocks_from_subblocks(s.subblock_energies(0), 4800)
+    listed = z[z >= ABS_GATE]
+    np.testing.assert_allclose(listed, ref["state"].gating_blocks(), rtol=ENERGY_RTOL)
+    s.close()
+
+
+def test_loud_to_quiet_transition_warmup(oracle):
+    """Worst case for the segment warm-up: -80 dB material right after 0 dBFS
+    low-frequency content, one sub-block per wave."""
+    from loudgain_amd.device import DeviceScanner
+    fs = 48000
+    t = np.arange(fs * 4) / fs
+    loud = 0.95 * np.sin(2 * np.pi * 30 * t)
+    rng = np.random.default_rng(1)
+    quiet = rng.standard_normal(fs * 6) * 1e-4
+    x = np.concatenate([loud, quiet])
+    pcm = synth.snap_s16_numpy(np.stack([x, x], 1))
+    ref = oracle.scan_track(pcm, fs)
+    s = DeviceScanner(0)
+    s.set_param("seg_subblocks", 1)
+    (got,), _ = s.scan([to_dev(pcm)], fs)
+    check_track(got, ref)
+    z = gating_blocks_from_subblocks(s.subblock_energies(0), 4800)
+    refz = ref["state"].gating_blocks()
+    listed = z[z >= ABS_GATE]
+    assert len(listed) == len(refz)
+    np.testing.assert_allclose(listed, refz, rtol=1e-7)
+    s.close()
+
+
+def test_album_parity(scanner, oracle):
+    specs = [(48000, 2, 33.3, 11), (48000, 2, 20.0, 12), (44100, 2, 25.5, 13), (48000, 1, 18.2, 14),
+             (96000, 2, 8.0, 15), (48000, 2, 0.2, 16)]
+    pcms = [synth.track_numpy(int(r * s), c, r, seed=sd, step_s=2.5) for r, c, s, sd in specs]
+    # make track 1 much quieter so the album relative gate differs from the per-track ones
+    pcms[1] = synth.snap_s16_numpy(pcms[1] * 0.03)
+    refs = [oracle.scan_track(p, sp[0]) for p, sp in zip(pcms, specs)]
+    states = [r["state"] for r in refs]
+    tracks, album = scanner.scan([to_dev(p) for p in pcms], [sp[0] for sp in specs], album=True)
+    for got, ref, sp in zip(tracks, refs, specs):
+        check_track(got, ref, rate=sp[0])
+    det = oracle.gating_detail(states)
+    assert album["n_abs"] == det["n_abs"] and album["n_rel"] == det["n_rel"]
+    assert abs(album["loudness"] - oracle.album_loudness(states)) <= 1e-6
+    assert abs(album["lra"] - oracle.album_lra(states)) <= 1e-6
+    assert abs(album["peak"] - max(r["peak"] for r in refs)) <= 1e-4
+    assert album["n_st"] == sum(r["n_st"] for r in refs)
+
+
+def test_errors(scanner):
+    import torch
+    from loudgain_amd.device import LoudscanError
+    x = torch.zeros((4800, 2), dtype=torch.float32, device="cuda")
+    with pytest.raises(LoudscanError):
+        scanner.plan([x], 15)            # rate < 16 (ebur128_init check)
+    with pytest.raises(LoudscanError):
+        scanner.plan([(x.data_ptr(), 4800, 0)], 48000)   # 0 channels
+    with pytest.raises(LoudscanError):
+        scanner.plan([(x.data_ptr(), 4800, 65)], 48000)  # > 64 channels
+    with pytest.raises(LoudscanError):
+        scanner.plan([(x.data_ptr() + 4, 100, 2)], 48000)  # misaligned
+    with pytest.raises(LoudscanError):
+        scanner.plan([x.cpu()], 48000)   # host memory is not accepted
+
+
+def test_ten_minutes_vs_oracle(scanner, oracle):
+    pcm = synth.track_numpy(48000 * 600, 2, 48000, seed=99)
+    ref = oracle.scan_track(pcm, 48000)
+    (got,), _ = scanner.scan([to_dev(pcm)], 48000)
+    check_track(got, ref)
