@@ -23,16 +23,19 @@
 extern "C" const int lgd_chunk_table[];
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
                                       const LgdFilt *F, hipStream_t s);
-extern "C" hipError_t lgd_launch_track_epilogue(const LgdTrackMeta *meta, int n_tracks,
-                                                const double *E, double *st, const float *peaks,
+extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_slices,
+                                                const LgdTrackMeta *meta, int n_tracks,
+                                                const double *E, double *Z, double *st,
+                                                const float *peaks, double *p1, double *p2,
                                                 double *res, double abs_gate, double rel_factor,
                                                 int do_tp, hipStream_t s);
 extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
                                      double minus20, hipStream_t s);
 extern "C" hipError_t lgd_launch_album_part1(const double *res, int n_tracks, double *part1,
                                              hipStream_t s);
-extern "C" hipError_t lgd_launch_album_stage2(const LgdTrackMeta *meta, int n_tracks,
-                                              const double *E, double *res, const double *part1,
+extern "C" hipError_t lgd_launch_album_stage2(const LgdSlice *slices, int n_slices,
+                                              const LgdTrackMeta *meta, const double *Z,
+                                              const double *p1, double *p2a, const double *part1,
                                               double *part2, double abs_gate, double rel_factor,
                                               hipStream_t s);
 extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *part2,
@@ -176,18 +179,21 @@ struct lgd_ctx {
   std::vector<LgdTrackMeta> meta;
   std::vector<LgdSeg> segs;
   std::vector<LgdRange> ranges;
+  std::vector<LgdSlice> slices;
   std::vector<Group> groups;
   uint64_t total_sb = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0, warm_bytes = 0;
   // device workspace
-  double *d_E = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
+  double *d_E = nullptr, *d_Z = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
+  double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr;  // per-slice gating partials
+  LgdSlice *d_slices = nullptr;
   double *d_part1 = nullptr, *d_part2 = nullptr;
   float *d_peaks = nullptr;
   LgdTrackMeta *d_meta = nullptr;
   LgdSeg *d_segs = nullptr;
   LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
   LgdRange *h_album_range = nullptr;  // pinned
-  size_t cap_E = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_meta = 0, cap_segs = 0,
-         cap_ranges = 0;
+  size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_meta = 0, cap_segs = 0,
+         cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0, cap_slices = 0;
   hipStream_t last_stream = nullptr;
   // ring of (start, scan kernel done, all done) event triples, one per execute
   static const int EV_RING = 64;
@@ -247,8 +253,9 @@ extern "C" lgd_ctx *lgd_create(int device) {
 extern "C" void lgd_destroy(lgd_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void *ptrs[] = {c->d_E, c->d_st, c->d_res, c->d_album, c->d_part1, c->d_part2, c->d_peaks,
-                  c->d_meta, c->d_segs, c->d_ranges, c->d_album_range};
+  void *ptrs[] = {c->d_E, c->d_Z, c->d_st, c->d_res, c->d_album, c->d_part1, c->d_part2, c->d_peaks,
+                  c->d_meta, c->d_segs, c->d_ranges, c->d_album_range, c->d_p1, c->d_p2, c->d_p2a,
+                  c->d_slices};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_album_range) (void)hipHostFree(c->h_album_range);
@@ -294,6 +301,7 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   c->meta.assign(n, LgdTrackMeta());
   c->segs.clear();
   c->ranges.clear();
+  c->slices.clear();
   c->groups.clear();
   c->total_sb = c->total_st = c->total_peak_floats = c->pcm_bytes = c->warm_bytes = 0;
 
@@ -319,6 +327,9 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     m.n_st_slots = m.n_sb >= 30 ? (m.n_sb - 30) / 10 + 1 : 0;
     m.sb_off = (long long)c->total_sb;
     m.st_off = (long long)c->total_st;
+    m.slice_off = (int)c->slices.size();
+    m.n_slices = m.n_sb >= 4 ? (m.n_sb - 3 + LGD_SLICE - 1) / LGD_SLICE : 0;
+    for (int sl = 0; sl < m.n_slices; ++sl) c->slices.push_back(LgdSlice{(int)t, sl * LGD_SLICE});
     c->total_sb += nsb;
     c->total_st += (uint64_t)m.n_st_slots;
     c->pcm_bytes += tr.frames * tr.channels * 4ull;
@@ -388,6 +399,11 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
 
   int rc;
   if ((rc = ensure(&c->d_E, &c->cap_E, c->total_sb))) return rc;
+  if ((rc = ensure(&c->d_Z, &c->cap_Z, c->total_sb))) return rc;
+  if ((rc = ensure(&c->d_p1, &c->cap_p1, 4 * c->slices.size()))) return rc;
+  if ((rc = ensure(&c->d_p2, &c->cap_p2, 2 * c->slices.size()))) return rc;
+  if ((rc = ensure(&c->d_p2a, &c->cap_p2a, 2 * c->slices.size()))) return rc;
+  if ((rc = ensure(&c->d_slices, &c->cap_slices, c->slices.size()))) return rc;
   if ((rc = ensure(&c->d_st, &c->cap_st, c->total_st))) return rc;
   if ((rc = ensure(&c->d_res, &c->cap_res, (size_t)n * LGR_STRIDE))) return rc;
   if ((rc = ensure(&c->d_peaks, &c->cap_peaks, c->total_peak_floats))) return rc;
@@ -412,6 +428,9 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   if (!c->segs.empty())
     HIPCHK(hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(LgdSeg),
                      hipMemcpyHostToDevice));
+  if (!c->slices.empty())
+    HIPCHK(hipMemcpy(c->d_slices, c->slices.data(), c->slices.size() * sizeof(LgdSlice),
+                     hipMemcpyHostToDevice));
   c->planned = true;
   return LGD_OK;
 }
@@ -419,8 +438,8 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
 extern "C" int lgd_album_stage2(lgd_ctx *c, void *hip_stream) {
   if (!c || !c->planned || !c->executed) return fail(LGD_ESTATE, "album stage 2 before execute");
   hipStream_t s = (hipStream_t)hip_stream;
-  HIPCHK(lgd_launch_album_stage2(c->d_meta, (int)c->tracks.size(), c->d_E, c->d_res, c->d_part1,
-                                 c->d_part2, c->abs_gate, c->rel_factor, s));
+  HIPCHK(lgd_launch_album_stage2(c->d_slices, (int)c->slices.size(), c->d_meta, c->d_Z, c->d_p1,
+                                 c->d_p2a, c->d_part1, c->d_part2, c->abs_gate, c->rel_factor, s));
   return LGD_OK;
 }
 
@@ -450,9 +469,9 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
     HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, c->d_segs + g.seg_begin, (int)g.seg_count,
                            &g.F, s));
   HIPCHK(hipEventRecord(ev[1], s));
-  HIPCHK(lgd_launch_track_epilogue(c->d_meta, n, c->d_E, c->d_st, c->d_peaks, c->d_res,
-                                   c->abs_gate, c->rel_factor,
-                                   (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
+  HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, c->d_E, c->d_Z,
+                                   c->d_st, c->d_peaks, c->d_p1, c->d_p2, c->d_res, c->abs_gate,
+                                   c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
   HIPCHK(lgd_launch_lra(c->d_ranges, n, c->d_st, c->minus20, s));
   c->executed = true;
   if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))

@@ -1,0 +1,412 @@
+// lgd_epilogue.hip -- gating, loudness-range and album kernels (gfx950).
+//
+// They replace the result queries that /root/reference/src/scan.c makes into
+// libebur128: E5/E6 block lists (ebur128_calc_gating_block /
+// energy_shortterm, reached from scan.c:448), E7 ebur128_loudness_global[_multiple]
+// (scan.c:294,383), E8 ebur128_loudness_range[_multiple] (scan.c:297,388), E9
+// ebur128_true_peak (scan.c:303,371) and the album peak loop (scan.c:359-378).
+//
+// Input: the 100 ms sub-block energies E[] and per-segment peaks written by
+// lgd_scan_kernel.  Everything is fp64; sums run in a fixed order (fixed slice
+// size, strided per-thread partials, fixed trees) so results are reproducible
+// and do not depend on how the scan was segmented.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "lgd_internal.h"
+
+#define LGD_WAVE 64
+#define LGD_EPI_NT 256
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, LGD_WAVE);
+  return v;
+}
+
+template <int NT>
+__device__ __forceinline__ double block_sum_f64(double v, double *sh) {
+  v = wave_sum_f64(v);
+  const int w = threadIdx.x / LGD_WAVE, l = threadIdx.x % LGD_WAVE;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < NT / LGD_WAVE; ++i) t += sh[i];
+  return t;
+}
+template <int NT>
+__device__ __forceinline__ double block_max_f64(double v, double *sh) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, LGD_WAVE));
+  const int w = threadIdx.x / LGD_WAVE, l = threadIdx.x % LGD_WAVE;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < NT / LGD_WAVE; ++i) t = fmax(t, sh[i]);
+  return t;
+}
+
+__device__ __forceinline__ double energy_to_loudness(double e) {
+  return 10.0 * (log(e) / log(10.0)) - 0.691;
+}
+
+// ---- pass 1: 400 ms block energies (E5), 3 s block energies (E6), absolute gate
+// p1[slice] = { n_abs, sum_abs, n_st, - }
+__global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
+    const LgdSlice *__restrict__ slices, const LgdTrackMeta *__restrict__ meta,
+    const double *__restrict__ E_all, double *__restrict__ Z_all, double *__restrict__ st_all,
+    double *__restrict__ p1, double abs_gate) {
+  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
+  const LgdSlice sl = slices[blockIdx.x];
+  const LgdTrackMeta m = meta[sl.track];
+  const double *E = E_all + m.sb_off;
+  double *Z = Z_all + m.sb_off;
+  const int tid = threadIdx.x;
+  const int nblk = m.n_sb - 3;
+  const int j1 = min(sl.j0 + LGD_SLICE, nblk);
+  // divide like the reference does (sum /= frames_per_block), not by a reciprocal
+  const double len4 = 4.0 * (double)m.s100, len30 = 30.0 * (double)m.s100;
+  double cnt = 0.0, sum = 0.0, cst = 0.0;
+  for (int j = sl.j0 + tid; j < j1; j += LGD_EPI_NT) {
+    const double zj = (((E[j] + E[j + 1]) + E[j + 2]) + E[j + 3]) / len4;
+    Z[j] = zj;
+    if (zj >= abs_gate) { cnt += 1.0; sum += zj; }
+  }
+  // short-term block kk ends at sub-block 10 kk + 30; it belongs to the slice
+  // that holds 400 ms block 10 kk
+  const int k0 = (sl.j0 + 9) / 10, k1 = min((sl.j0 + LGD_SLICE + 9) / 10, m.n_st_slots);
+  for (int kk = k0 + tid; kk < k1; kk += LGD_EPI_NT) {
+    const double *p = E + 10 * kk;
+    double s = 0.0;
+#pragma unroll 6
+    for (int i = 0; i < 30; ++i) s += p[i];
+    s /= len30;
+    const bool listed = s >= abs_gate;
+    st_all[m.st_off + kk] = listed ? s : 0.0;  // 0.0 == not listed
+    cst += listed ? 1.0 : 0.0;
+  }
+  cnt = block_sum_f64<LGD_EPI_NT>(cnt, sh);
+  sum = block_sum_f64<LGD_EPI_NT>(sum, sh);
+  cst = block_sum_f64<LGD_EPI_NT>(cst, sh);
+  if (tid == 0) {
+    double *o = p1 + 4 * (size_t)blockIdx.x;
+    o[0] = cnt; o[1] = sum; o[2] = cst; o[3] = 0.0;
+  }
+}
+
+// ---- pass 2: relative gate (E7).  thr comes from this track's own pass-1 totals
+// or, for the album pass, from the (possibly all-reduced) album part1.
+// p2[slice] = { n_rel, sum_rel }
+__global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass2(
+    const LgdSlice *__restrict__ slices, const LgdTrackMeta *__restrict__ meta,
+    const double *__restrict__ Z_all, const double *__restrict__ p1, double *__restrict__ p2,
+    const double *__restrict__ album_part1, double abs_gate, double rel_factor) {
+  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
+  const LgdSlice sl = slices[blockIdx.x];
+  const LgdTrackMeta m = meta[sl.track];
+  const double *Z = Z_all + m.sb_off;
+  const int tid = threadIdx.x;
+  const int j1 = min(sl.j0 + LGD_SLICE, m.n_sb - 3);
+  double n_abs, sum_abs;
+  if (album_part1) {
+    sum_abs = album_part1[0];
+    n_abs = album_part1[1];
+  } else {
+    double a = 0.0, b = 0.0;
+    for (int i = tid; i < m.n_slices; i += LGD_EPI_NT) {
+      a += p1[4 * (size_t)(m.slice_off + i) + 0];
+      b += p1[4 * (size_t)(m.slice_off + i) + 1];
+    }
+    n_abs = block_sum_f64<LGD_EPI_NT>(a, sh);
+    sum_abs = block_sum_f64<LGD_EPI_NT>(b, sh);
+  }
+  double thr = 0.0;
+  if (n_abs > 0.0) {
+    thr = sum_abs / n_abs;
+    thr *= rel_factor;
+  }
+  double cnt = 0.0, sum = 0.0;
+  for (int j = sl.j0 + tid; j < j1; j += LGD_EPI_NT) {
+    const double zj = Z[j];
+    if (zj >= abs_gate && zj >= thr) { cnt += 1.0; sum += zj; }
+  }
+  cnt = block_sum_f64<LGD_EPI_NT>(cnt, sh);
+  sum = block_sum_f64<LGD_EPI_NT>(sum, sh);
+  if (tid == 0) {
+    p2[2 * (size_t)blockIdx.x + 0] = cnt;
+    p2[2 * (size_t)blockIdx.x + 1] = sum;
+  }
+}
+
+// ---- per-track result record (E7 loudness, E9 peaks, counts) ----------------
+__global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
+    const LgdTrackMeta *__restrict__ meta, const double *__restrict__ p1,
+    const double *__restrict__ p2, const float *__restrict__ peaks, double *__restrict__ res_all,
+    double rel_factor, int do_tp) {
+  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
+  const LgdTrackMeta m = meta[blockIdx.x];
+  double *res = res_all + (size_t)blockIdx.x * LGR_STRIDE;
+  const int tid = threadIdx.x;
+  double a = 0.0, b = 0.0, c = 0.0, d = 0.0, e = 0.0;
+  for (int i = tid; i < m.n_slices; i += LGD_EPI_NT) {
+    const size_t s = (size_t)(m.slice_off + i);
+    a += p1[4 * s + 0];
+    b += p1[4 * s + 1];
+    c += p1[4 * s + 2];
+    d += p2[2 * s + 0];
+    e += p2[2 * s + 1];
+  }
+  const double n_abs = block_sum_f64<LGD_EPI_NT>(a, sh);
+  const double sum_abs = block_sum_f64<LGD_EPI_NT>(b, sh);
+  const double n_st = block_sum_f64<LGD_EPI_NT>(c, sh);
+  const double n_rel = block_sum_f64<LGD_EPI_NT>(d, sh);
+  const double sum_rel = block_sum_f64<LGD_EPI_NT>(e, sh);
+  double sp = 0.0, tp = 0.0;
+  for (int i = tid; i < m.n_seg * m.nch; i += LGD_EPI_NT) {
+    const int sgi = i / m.nch, ch = i % m.nch;
+    const float *pp = peaks + m.peak_off + (size_t)sgi * 2 * m.nch;
+    sp = fmax(sp, (double)pp[ch]);
+    tp = fmax(tp, (double)pp[m.nch + ch]);
+  }
+  sp = block_max_f64<LGD_EPI_NT>(sp, sh);
+  tp = block_max_f64<LGD_EPI_NT>(tp, sh);
+  if (tid == 0) {
+    double thr = 0.0;
+    if (n_abs > 0.0) {
+      thr = sum_abs / n_abs;
+      thr *= rel_factor;
+    }
+    res[LGR_LOUDNESS] = n_rel > 0.0 ? energy_to_loudness(sum_rel / n_rel) : -HUGE_VAL;
+    res[LGR_PEAK] = do_tp ? fmax(sp, tp) : sp;
+    res[LGR_SPEAK] = sp;
+    res[LGR_TPEAK] = do_tp ? tp : 0.0;
+    res[LGR_THR] = thr;
+    res[LGR_SUM_ABS] = sum_abs;
+    res[LGR_SUM_REL] = sum_rel;
+    res[LGR_NBLK] = (double)(m.n_sb >= 4 ? m.n_sb - 3 : 0);
+    res[LGR_NABS] = n_abs;
+    res[LGR_NREL] = n_rel;
+    res[LGR_NSTBLK] = (double)m.n_st_slots;
+    res[LGR_NST] = n_st;
+  }
+}
+
+// ---- E8: loudness range of the listed short-term energies in st[off, off+n).
+// Exact: libebur128 sorts and indexes; here the two order statistics are found
+// by an MSB-first radix select over the IEEE bit patterns (positive doubles
+// order like their bits), so no sort and no histogram quantisation.  Up to
+// LGD_LRA_CAP energies are staged in LDS once; longer inputs stream from L2.
+#define LGD_LRA_NT 1024
+#define LGD_LRA_CAP 7168  // doubles in LDS (56 KiB)
+
+__global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__restrict__ ranges,
+                                                            const double *__restrict__ st_base,
+                                                            double minus20) {
+  __shared__ double sh[LGD_LRA_NT / LGD_WAVE];
+  __shared__ double cache[LGD_LRA_CAP];
+  __shared__ unsigned hist[2][256];
+  __shared__ unsigned long long s_prefix[2];
+  __shared__ unsigned long long s_rank[2];
+  const LgdRange rg = ranges[blockIdx.x];
+  const double *gv = st_base + rg.off;
+  const int tid = threadIdx.x;
+  const bool in_lds = rg.n <= LGD_LRA_CAP;
+  if (in_lds)
+    for (long long i = tid; i < rg.n; i += LGD_LRA_NT) cache[i] = gv[i];
+  __syncthreads();
+#define LRA_AT(i) (in_lds ? cache[i] : gv[i])
+
+  double cnt = 0.0, sum = 0.0;
+  for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {
+    const double x = LRA_AT(i);
+    if (x > 0.0) { cnt += 1.0; sum += x; }
+  }
+  const double n = block_sum_f64<LGD_LRA_NT>(cnt, sh);
+  const double S = block_sum_f64<LGD_LRA_NT>(sum, sh);
+  if (n == 0.0) {
+    if (tid == 0) *rg.out = 0.0;
+    return;
+  }
+  const double power = S / n;
+  const double integrated = minus20 * power;
+  cnt = 0.0;
+  for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {
+    const double x = LRA_AT(i);
+    if (x > 0.0 && !(x < integrated)) cnt += 1.0;
+  }
+  const double mrem = block_sum_f64<LGD_LRA_NT>(cnt, sh);
+  if (mrem == 0.0) {
+    if (tid == 0) *rg.out = 0.0;
+    return;
+  }
+  if (tid == 0) {
+    const unsigned long long dropped = (unsigned long long)(n - mrem);
+    s_rank[0] = dropped + (unsigned long long)((mrem - 1.0) * 0.95 + 0.5);
+    s_rank[1] = dropped + (unsigned long long)((mrem - 1.0) * 0.1 + 0.5);
+    s_prefix[0] = s_prefix[1] = 0ull;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < 8; ++pass) {
+    const int sh_bits = 56 - 8 * pass;
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (sh_bits + 8));
+    if (tid < 512) hist[tid >> 8][tid & 255] = 0u;
+    __syncthreads();
+    const unsigned long long p0 = s_prefix[0], p1 = s_prefix[1];
+    for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {
+      const double x = LRA_AT(i);
+      if (x > 0.0) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+        const unsigned dg = (unsigned)((key >> sh_bits) & 0xffu);
+        if ((key & himask) == p0) atomicAdd(&hist[0][dg], 1u);
+        if ((key & himask) == p1) atomicAdd(&hist[1][dg], 1u);
+      }
+    }
+    __syncthreads();
+    // waves 0 and 1 each locate their rank's digit: lane l owns bins 4l..4l+3
+    if (tid < 2 * LGD_WAVE) {
+      const int which = tid / LGD_WAVE, l = tid % LGD_WAVE;
+      const unsigned h0 = hist[which][4 * l], h1 = hist[which][4 * l + 1],
+                     h2 = hist[which][4 * l + 2], h3 = hist[which][4 * l + 3];
+      unsigned long long incl = (unsigned long long)h0 + h1 + h2 + h3;
+#pragma unroll
+      for (int d = 1; d < LGD_WAVE; d <<= 1) {
+        const unsigned long long up = __shfl_up(incl, d, LGD_WAVE);
+        if (l >= d) incl += up;
+      }
+      const unsigned long long r = s_rank[which];
+      const unsigned long long excl = incl - ((unsigned long long)h0 + h1 + h2 + h3);
+      if (excl <= r && r < incl) {  // exactly one lane
+        unsigned long long c = excl;
+        int dg = 4 * l;
+        if (c + h0 <= r) { c += h0; ++dg;
+          if (c + h1 <= r) { c += h1; ++dg;
+            if (c + h2 <= r) { c += h2; ++dg; } } }
+        s_rank[which] = r - c;
+        s_prefix[which] |= ((unsigned long long)dg) << sh_bits;
+      }
+    }
+    __syncthreads();
+  }
+#undef LRA_AT
+  if (tid == 0) {
+    const double h_en = __longlong_as_double((long long)s_prefix[0]);
+    const double l_en = __longlong_as_double((long long)s_prefix[1]);
+    *rg.out = energy_to_loudness(h_en) - energy_to_loudness(l_en);
+  }
+}
+
+// ---- album stages (scan.c:359-405) ---------------------------------------
+// part1 = { sum_abs, n_abs, peak, n_st } over this rank's tracks
+__global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part1_kernel(const double *__restrict__ res,
+                                                                    int n_tracks,
+                                                                    double *__restrict__ part1) {
+  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
+  double sa = 0.0, na = 0.0, pk = 0.0, ns = 0.0;
+  for (int t = threadIdx.x; t < n_tracks; t += LGD_EPI_NT) {
+    const double *r = res + (size_t)t * LGR_STRIDE;
+    sa += r[LGR_SUM_ABS];
+    na += r[LGR_NABS];
+    ns += r[LGR_NST];
+    pk = fmax(pk, r[LGR_PEAK]);
+  }
+  sa = block_sum_f64<LGD_EPI_NT>(sa, sh);
+  na = block_sum_f64<LGD_EPI_NT>(na, sh);
+  ns = block_sum_f64<LGD_EPI_NT>(ns, sh);
+  pk = block_max_f64<LGD_EPI_NT>(pk, sh);
+  if (threadIdx.x == 0) {
+    part1[0] = sa; part1[1] = na; part1[2] = pk; part1[3] = ns;
+  }
+}
+
+// part2 = { sum_rel, n_rel } over all slices of this rank (album second pass)
+__global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part2_kernel(const double *__restrict__ p2a,
+                                                                    int n_slices,
+                                                                    double *__restrict__ part2) {
+  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
+  double sr = 0.0, nr = 0.0;
+  for (int i = threadIdx.x; i < n_slices; i += LGD_EPI_NT) {
+    nr += p2a[2 * (size_t)i + 0];
+    sr += p2a[2 * (size_t)i + 1];
+  }
+  sr = block_sum_f64<LGD_EPI_NT>(sr, sh);
+  nr = block_sum_f64<LGD_EPI_NT>(nr, sh);
+  if (threadIdx.x == 0) {
+    part2[0] = sr; part2[1] = nr;
+  }
+}
+
+// album[] = { loudness, lra (lgd_lra_kernel), peak, thr, sum_abs, sum_rel, n_abs, n_rel, n_st }
+__global__ void lgd_album_final_kernel(const double *__restrict__ part1,
+                                       const double *__restrict__ part2, double rel_factor,
+                                       double *__restrict__ album) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double thr = 0.0;
+  if (part1[1] > 0.0) {
+    thr = part1[0] / part1[1];
+    thr *= rel_factor;
+  }
+  album[0] = part2[1] > 0.0 ? energy_to_loudness(part2[0] / part2[1]) : -HUGE_VAL;
+  album[2] = part1[2];
+  album[3] = thr;
+  album[4] = part1[0];
+  album[5] = part2[0];
+  album[6] = part1[1];
+  album[7] = part2[1];
+  album[8] = part1[3];
+}
+
+// ------------------------------------------------------- launch wrappers ---
+extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_slices,
+                                                const LgdTrackMeta *meta, int n_tracks,
+                                                const double *E, double *Z, double *st,
+                                                const float *peaks, double *p1, double *p2,
+                                                double *res, double abs_gate, double rel_factor,
+                                                int do_tp, hipStream_t s) {
+  if (n_tracks <= 0) return hipSuccess;
+  if (n_slices > 0) {
+    hipLaunchKernelGGL(lgd_gate_pass1, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, E, Z, st,
+                       p1, abs_gate);
+    hipLaunchKernelGGL(lgd_gate_pass2, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, Z, p1, p2,
+                       (const double *)nullptr, abs_gate, rel_factor);
+  }
+  hipLaunchKernelGGL(lgd_track_final, dim3(n_tracks), dim3(LGD_EPI_NT), 0, s, meta, p1, p2, peaks, res,
+                     rel_factor, do_tp);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
+                                     double minus20, hipStream_t s) {
+  if (n_ranges <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lgd_lra_kernel, dim3(n_ranges), dim3(LGD_LRA_NT), 0, s,
+                     (const LgdRange *)ranges, st_base, minus20);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t lgd_launch_album_part1(const double *res, int n_tracks, double *part1,
+                                             hipStream_t s) {
+  hipLaunchKernelGGL(lgd_album_part1_kernel, dim3(1), dim3(LGD_EPI_NT), 0, s, res, n_tracks, part1);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t lgd_launch_album_stage2(const LgdSlice *slices, int n_slices,
+                                              const LgdTrackMeta *meta, const double *Z,
+                                              const double *p1, double *p2a, const double *part1,
+                                              double *part2, double abs_gate, double rel_factor,
+                                              hipStream_t s) {
+  if (n_slices > 0)
+    hipLaunchKernelGGL(lgd_gate_pass2, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, Z, p1, p2a,
+                       part1, abs_gate, rel_factor);
+  hipLaunchKernelGGL(lgd_album_part2_kernel, dim3(1), dim3(LGD_EPI_NT), 0, s, p2a, n_slices, part2);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *part2,
+                                             double rel_factor, double *album, hipStream_t s) {
+  hipLaunchKernelGGL(lgd_album_final_kernel, dim3(1), dim3(1), 0, s, part1, part2, rel_factor, album);
+  return hipGetLastError();
+}

@@ -35,8 +35,19 @@ struct LgdFilt {
   int pad;
 };
 
+// The gating epilogue walks the 400 ms blocks of a track in slices of this many
+// blocks, one workgroup per slice (fixed size -> fixed, reproducible summation
+// tree, independent of how the scan kernel was segmented).
+#define LGD_SLICE 1024
+
+struct LgdSlice {
+  int track;
+  int j0;             // first 400 ms block of the slice
+};
+
 struct LgdTrackMeta {
   long long sb_off;   // first slot of this track in the sub-block energy array
+                      // (and of its 400 ms block energies in the Z array)
   long long st_off;   // first slot in the short-term energy array
   long long peak_off; // first float of this track's [n_seg][2][nch] peak partials
   int n_sb;           // whole sub-blocks
@@ -44,6 +55,8 @@ struct LgdTrackMeta {
   int n_seg;
   int s100;
   int nch;
+  int slice_off;      // first epilogue slice of this track
+  int n_slices;       // ceil((n_sb - 3) / LGD_SLICE), 0 if n_sb < 4
   int pad;
 };
 

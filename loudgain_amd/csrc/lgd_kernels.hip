@@ -4,9 +4,7 @@
 // /root/reference/src/scan.c:448 and :294-303,:383-388):
 //   lgd_scan_kernel      E3 K-weighting (K2) + sample peak (K1) + E4 true peak
 //                        (K3) + the 100 ms partial sums behind E5/E6 (K4)
-//   lgd_track_epilogue   E5/E6 block lists + E7 two-pass gating + E9 peaks
-//   lgd_lra_kernel       E8 loudness range (exact rank selection, no sort)
-//   lgd_album_*          E7/E8 "_multiple" forms + scan.c:359-378 album peak
+// (the gating / LRA / album epilogue kernels live in lgd_epilogue.hip)
 //
 // Parallelisation of the strictly sequential IIR:
 // one wavefront owns a run of whole 100 ms sub-blocks.  It walks that run in
@@ -39,6 +37,14 @@
 #include "lgd_internal.h"
 
 #define LGD_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Pointers that arrive inside a descriptor in memory lose their address space and
+// compile to flat_* accesses, which count in lgkmcnt too: every LDS wait would
+// then also wait for the prefetched tile.  These casts make them global_*.
+#define LGD_GLOBAL __attribute__((address_space(1)))
+typedef const f32x4 LGD_GLOBAL *gvec_ptr;
+typedef const float LGD_GLOBAL *gflt_ptr;
 
 // ---------------------------------------------------------------- helpers ---
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -98,29 +104,58 @@ __global__ __launch_bounds__(LGD_WAVE) void lgd_scan_kernel(const LgdSeg *__rest
 
   const int n_main = (int)((sg.f_peak_end - sg.f0 + K::TILE_F - 1) / K::TILE_F);
 
+  // ---- tile staging: coalesced 16-B loads -> registers -> LDS.  The NEXT tile's
+  // loads are issued before the current tile is computed (software prefetch,
+  // NV float4 per lane in flight); tiles touching a track edge take the guarded
+  // path, where frames outside [0, n_frames) read as zero.
+  constexpr int NV = (K::NVEC + LGD_WAVE - 1) / LGD_WAVE;
+  f32x4 pf[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) pf[i] = (f32x4)(0.f);
+  bool pf_valid = false;
+#define LGD_TILE_G0(kk) ((sg.f0 + (long long)(kk) * K::TILE_F - K::HALO) * NCH - shift)
+#define LGD_PREFETCH(kk)                                                                \
+  do {                                                                                  \
+    const long long g0_ = LGD_TILE_G0(kk); /* float index of lds[0], multiple of 4 */   \
+    pf_valid = (g0_ >= 0) && (g0_ + 4LL * K::NVEC <= sg.n_floats); /* wave-uniform */   \
+    if (pf_valid) {                                                                     \
+      const gvec_ptr src_ = (gvec_ptr)(sg.pcm + g0_);                                   \
+      _Pragma("unroll") for (int i_ = 0; i_ < NV; ++i_) {                               \
+        const int idx_ = lane + LGD_WAVE * i_;                                          \
+        if (i_ + 1 < NV || idx_ < K::NVEC) pf[i_] = src_[idx_];                         \
+      }                                                                                 \
+    }                                                                                   \
+  } while (0)
+  if (-sg.n_warm_tiles < n_main) LGD_PREFETCH(-sg.n_warm_tiles);
+
   for (int k = -sg.n_warm_tiles; k < n_main; ++k) {
     const long long tb = sg.f0 + (long long)k * K::TILE_F;  // first frame of the tile
-    // ---- stage the tile (plus HALO frames of history) through LDS ---------
-    // coalesced 16-B loads; frames outside [0, n_frames) read as zero
     __syncthreads();  // previous tile's LDS reads are done
-    {
-      const long long g0 = (tb - K::HALO) * NCH - shift;  // float index of lds[0], 4-aligned
-#pragma unroll 4
+    if (pf_valid) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int idx = lane + LGD_WAVE * i;
+        if (i + 1 < NV || idx < K::NVEC) *reinterpret_cast<f32x4 *>(lds + 4 * idx) = pf[i];
+      }
+    } else {
+      const long long g0 = LGD_TILE_G0(k);
       for (int i = lane; i < K::NVEC; i += LGD_WAVE) {
         const long long g = g0 + 4LL * i;
-        float4 v;
+        const gflt_ptr gp = (gflt_ptr)sg.pcm;
+        f32x4 v;
         if (g >= 0 && g + 3 < sg.n_floats) {
-          v = *reinterpret_cast<const float4 *>(sg.pcm + g);
+          v = *(gvec_ptr)(sg.pcm + g);
         } else {
-          v.x = (g + 0 >= 0 && g + 0 < sg.n_floats) ? sg.pcm[g + 0] : 0.f;
-          v.y = (g + 1 >= 0 && g + 1 < sg.n_floats) ? sg.pcm[g + 1] : 0.f;
-          v.z = (g + 2 >= 0 && g + 2 < sg.n_floats) ? sg.pcm[g + 2] : 0.f;
-          v.w = (g + 3 >= 0 && g + 3 < sg.n_floats) ? sg.pcm[g + 3] : 0.f;
+          v.x = (g + 0 >= 0 && g + 0 < sg.n_floats) ? gp[g + 0] : 0.f;
+          v.y = (g + 1 >= 0 && g + 1 < sg.n_floats) ? gp[g + 1] : 0.f;
+          v.z = (g + 2 >= 0 && g + 2 < sg.n_floats) ? gp[g + 2] : 0.f;
+          v.w = (g + 3 >= 0 && g + 3 < sg.n_floats) ? gp[g + 3] : 0.f;
         }
-        *reinterpret_cast<float4 *>(lds + 4 * i) = v;
+        *reinterpret_cast<f32x4 *>(lds + 4 * i) = v;
       }
     }
     __syncthreads();
+    if (k + 1 < n_main) LGD_PREFETCH(k + 1); else pf_valid = false;
 
     // this lane's chunk: frames [tb + lane*C, +C), streamed from LDS U frames at a
     // time (keeps the VGPR count low; LDS reads are ~free next to the fp64 work)
@@ -314,7 +349,7 @@ __global__ __launch_bounds__(LGD_WAVE) void lgd_scan_kernel(const LgdSeg *__rest
       acc += mine ? e : 0.0;
       if ((long long)k * LGD_WAVE + LGD_WAVE >= cur_q + F.lps) {  // `cur` ends in this tile
         const double tot = wave_sum_f64(acc);
-        if (lane == 0 && cur < sg.n_sb) sg.e_out[cur] = tot;
+        if (lane == 0 && cur < sg.n_sb) ((double LGD_GLOBAL *)sg.e_out)[cur] = tot;
         acc = 0.0;
         ++cur;
         cur_q += F.lps;
@@ -330,285 +365,10 @@ __global__ __launch_bounds__(LGD_WAVE) void lgd_scan_kernel(const LgdSeg *__rest
     const float s = wave_max_f32(pk_s[ch]);
     const float t = wave_max_f32(pk_t[ch]);
     if (lane == 0) {
-      sg.peak_out[ch] = s;
-      sg.peak_out[NCH + ch] = t;
+      ((float LGD_GLOBAL *)sg.peak_out)[ch] = s;
+      ((float LGD_GLOBAL *)sg.peak_out)[NCH + ch] = t;
     }
   }
-}
-
-// ------------------------------------------------------- block reductions ---
-template <int NT>
-__device__ __forceinline__ double block_sum_f64(double v, double *sh) {
-  v = wave_sum_f64(v);
-  const int w = threadIdx.x / LGD_WAVE, l = threadIdx.x % LGD_WAVE;
-  __syncthreads();
-  if (l == 0) sh[w] = v;
-  __syncthreads();
-  double t = 0.0;
-#pragma unroll
-  for (int i = 0; i < NT / LGD_WAVE; ++i) t += sh[i];
-  return t;
-}
-template <int NT>
-__device__ __forceinline__ double block_max_f64(double v, double *sh) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, LGD_WAVE));
-  const int w = threadIdx.x / LGD_WAVE, l = threadIdx.x % LGD_WAVE;
-  __syncthreads();
-  if (l == 0) sh[w] = v;
-  __syncthreads();
-  double t = 0.0;
-#pragma unroll
-  for (int i = 0; i < NT / LGD_WAVE; ++i) t = fmax(t, sh[i]);
-  return t;
-}
-
-// E5/E6/E7/E9 for one track per workgroup.
-#define LGD_EPI_NT 256
-__global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_epilogue(
-    const LgdTrackMeta *__restrict__ meta, const double *__restrict__ E_all,
-    double *__restrict__ st_all, const float *__restrict__ peaks, double *__restrict__ res_all,
-    double abs_gate, double rel_factor, int do_tp) {
-  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
-  const LgdTrackMeta m = meta[blockIdx.x];
-  const double *E = E_all + m.sb_off;
-  double *res = res_all + (size_t)blockIdx.x * LGR_STRIDE;
-  const int tid = threadIdx.x;
-  const int nblk = m.n_sb >= 4 ? m.n_sb - 3 : 0;
-  // divide like the reference does (sum /= frames_per_block), not by a reciprocal
-  const double len4 = 4.0 * (double)m.s100, len30 = 30.0 * (double)m.s100;
-
-  double cnt = 0.0, sum = 0.0;
-  for (int j = tid; j < nblk; j += LGD_EPI_NT) {
-    const double zj = (((E[j] + E[j + 1]) + E[j + 2]) + E[j + 3]) / len4;
-    if (zj >= abs_gate) { cnt += 1.0; sum += zj; }
-  }
-  const double n_abs = block_sum_f64<LGD_EPI_NT>(cnt, sh);
-  const double sum_abs = block_sum_f64<LGD_EPI_NT>(sum, sh);
-  double thr = 0.0, n_rel = 0.0, sum_rel = 0.0;
-  if (n_abs > 0.0) {
-    thr = sum_abs / n_abs;
-    thr *= rel_factor;
-    cnt = 0.0; sum = 0.0;
-    for (int j = tid; j < nblk; j += LGD_EPI_NT) {
-      const double zj = (((E[j] + E[j + 1]) + E[j + 2]) + E[j + 3]) / len4;
-      if (zj >= abs_gate && zj >= thr) { cnt += 1.0; sum += zj; }
-    }
-    n_rel = block_sum_f64<LGD_EPI_NT>(cnt, sh);
-    sum_rel = block_sum_f64<LGD_EPI_NT>(sum, sh);
-  }
-  // short-term (3 s) blocks, 1 s cadence
-  cnt = 0.0;
-  for (int kk = tid; kk < m.n_st_slots; kk += LGD_EPI_NT) {
-    double s = 0.0;
-    const double *p = E + 10 * kk;
-    for (int i = 0; i < 30; ++i) s += p[i];
-    s /= len30;
-    const bool listed = s >= abs_gate;
-    st_all[m.st_off + kk] = listed ? s : 0.0;
-    cnt += listed ? 1.0 : 0.0;
-  }
-  const double n_st = block_sum_f64<LGD_EPI_NT>(cnt, sh);
-  // peaks over segment partials (all channels)
-  double sp = 0.0, tp = 0.0;
-  for (int i = tid; i < m.n_seg * m.nch; i += LGD_EPI_NT) {
-    const int sgi = i / m.nch, ch = i % m.nch;
-    const float *pp = peaks + m.peak_off + (size_t)sgi * 2 * m.nch;
-    sp = fmax(sp, (double)pp[ch]);
-    tp = fmax(tp, (double)pp[m.nch + ch]);
-  }
-  sp = block_max_f64<LGD_EPI_NT>(sp, sh);
-  tp = block_max_f64<LGD_EPI_NT>(tp, sh);
-  if (tid == 0) {
-    res[LGR_LOUDNESS] = n_rel > 0.0 ? 10.0 * (log(sum_rel / n_rel) / log(10.0)) - 0.691 : -HUGE_VAL;
-    res[LGR_PEAK] = do_tp ? fmax(sp, tp) : sp;
-    res[LGR_SPEAK] = sp;
-    res[LGR_TPEAK] = do_tp ? tp : 0.0;
-    res[LGR_THR] = thr;
-    res[LGR_SUM_ABS] = sum_abs;
-    res[LGR_SUM_REL] = sum_rel;
-    res[LGR_NBLK] = (double)nblk;
-    res[LGR_NABS] = n_abs;
-    res[LGR_NREL] = n_rel;
-    res[LGR_NSTBLK] = (double)m.n_st_slots;
-    res[LGR_NST] = n_st;
-  }
-}
-
-// E8: loudness range of the listed short-term energies in st[off, off+n).
-// Exact: libebur128 sorts and indexes; here the two order statistics are found
-// by an MSB-first radix select over the IEEE bit patterns (positive doubles
-// order like their bits), so no sort and no histogram quantisation.
-#define LGD_LRA_NT 256
-
-__global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__restrict__ ranges,
-                                                            const double *__restrict__ st_base,
-                                                            double minus20) {
-  __shared__ double sh[LGD_LRA_NT / LGD_WAVE];
-  __shared__ unsigned hist[2][256];
-  __shared__ unsigned long long s_prefix[2];
-  __shared__ unsigned long long s_rank[2];
-  const LgdRange rg = ranges[blockIdx.x];
-  const double *v = st_base + rg.off;
-  const int tid = threadIdx.x;
-
-  double cnt = 0.0, sum = 0.0;
-  for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {
-    const double x = v[i];
-    if (x > 0.0) { cnt += 1.0; sum += x; }
-  }
-  const double n = block_sum_f64<LGD_LRA_NT>(cnt, sh);
-  const double S = block_sum_f64<LGD_LRA_NT>(sum, sh);
-  if (n == 0.0) {
-    if (tid == 0) *rg.out = 0.0;
-    return;
-  }
-  const double power = S / n;
-  const double integrated = minus20 * power;
-  cnt = 0.0;
-  for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {
-    const double x = v[i];
-    if (x > 0.0 && !(x < integrated)) cnt += 1.0;
-  }
-  const double mrem = block_sum_f64<LGD_LRA_NT>(cnt, sh);
-  if (mrem == 0.0) {
-    if (tid == 0) *rg.out = 0.0;
-    return;
-  }
-  if (tid == 0) {
-    const unsigned long long dropped = (unsigned long long)(n - mrem);
-    s_rank[0] = dropped + (unsigned long long)((mrem - 1.0) * 0.95 + 0.5);
-    s_rank[1] = dropped + (unsigned long long)((mrem - 1.0) * 0.1 + 0.5);
-    s_prefix[0] = s_prefix[1] = 0ull;
-  }
-  __syncthreads();
-  for (int pass = 0; pass < 8; ++pass) {
-    const int sh_bits = 56 - 8 * pass;
-    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (sh_bits + 8));
-    hist[0][tid] = 0u;
-    hist[1][tid] = 0u;
-    __syncthreads();
-    const unsigned long long p0 = s_prefix[0], p1 = s_prefix[1];
-    for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {
-      const double x = v[i];
-      if (x > 0.0) {
-        const unsigned long long key = (unsigned long long)__double_as_longlong(x);
-        const unsigned dg = (unsigned)((key >> sh_bits) & 0xffu);
-        if ((key & himask) == p0) atomicAdd(&hist[0][dg], 1u);
-        if ((key & himask) == p1) atomicAdd(&hist[1][dg], 1u);
-      }
-    }
-    __syncthreads();
-    if (tid < 2) {
-      unsigned long long r = s_rank[tid], c = 0;
-      int dg = 0;
-      for (; dg < 256; ++dg) {
-        const unsigned long long h = hist[tid][dg];
-        if (c + h > r) break;
-        c += h;
-      }
-      s_rank[tid] = r - c;
-      s_prefix[tid] |= ((unsigned long long)dg) << sh_bits;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    const double h_en = __longlong_as_double((long long)s_prefix[0]);
-    const double l_en = __longlong_as_double((long long)s_prefix[1]);
-    const double lh = 10.0 * (log(h_en) / log(10.0)) - 0.691;
-    const double ll = 10.0 * (log(l_en) / log(10.0)) - 0.691;
-    *rg.out = lh - ll;
-  }
-}
-
-// ---- album stages (scan.c:359-405) ---------------------------------------
-// part1 = { sum_abs, n_abs, peak, n_st } over this rank's tracks
-__global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part1_kernel(const double *__restrict__ res,
-                                                                    int n_tracks,
-                                                                    double *__restrict__ part1) {
-  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
-  double sa = 0.0, na = 0.0, pk = 0.0, ns = 0.0;
-  for (int t = threadIdx.x; t < n_tracks; t += LGD_EPI_NT) {
-    const double *r = res + (size_t)t * LGR_STRIDE;
-    sa += r[LGR_SUM_ABS];
-    na += r[LGR_NABS];
-    ns += r[LGR_NST];
-    pk = fmax(pk, r[LGR_PEAK]);
-  }
-  sa = block_sum_f64<LGD_EPI_NT>(sa, sh);
-  na = block_sum_f64<LGD_EPI_NT>(na, sh);
-  ns = block_sum_f64<LGD_EPI_NT>(ns, sh);
-  pk = block_max_f64<LGD_EPI_NT>(pk, sh);
-  if (threadIdx.x == 0) {
-    part1[0] = sa; part1[1] = na; part1[2] = pk; part1[3] = ns;
-  }
-}
-
-// second gating pass of every track against the ALBUM relative threshold
-__global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_pass2_kernel(
-    const LgdTrackMeta *__restrict__ meta, const double *__restrict__ E_all,
-    double *__restrict__ res_all, const double *__restrict__ part1, double abs_gate,
-    double rel_factor) {
-  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
-  const LgdTrackMeta m = meta[blockIdx.x];
-  const double *E = E_all + m.sb_off;
-  double *res = res_all + (size_t)blockIdx.x * LGR_STRIDE;
-  const int nblk = m.n_sb >= 4 ? m.n_sb - 3 : 0;
-  const double len4 = 4.0 * (double)m.s100;
-  double thr = 0.0;
-  if (part1[1] > 0.0) {
-    thr = part1[0] / part1[1];
-    thr *= rel_factor;
-  }
-  double cnt = 0.0, sum = 0.0;
-  for (int j = threadIdx.x; j < nblk; j += LGD_EPI_NT) {
-    const double zj = (((E[j] + E[j + 1]) + E[j + 2]) + E[j + 3]) / len4;
-    if (zj >= abs_gate && zj >= thr) { cnt += 1.0; sum += zj; }
-  }
-  cnt = block_sum_f64<LGD_EPI_NT>(cnt, sh);
-  sum = block_sum_f64<LGD_EPI_NT>(sum, sh);
-  if (threadIdx.x == 0) {
-    res[LGR_ALB_NREL] = cnt;
-    res[LGR_ALB_SUM_REL] = sum;
-  }
-}
-
-// part2 = { sum_rel, n_rel } over this rank's tracks
-__global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part2_kernel(const double *__restrict__ res,
-                                                                    int n_tracks,
-                                                                    double *__restrict__ part2) {
-  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
-  double sr = 0.0, nr = 0.0;
-  for (int t = threadIdx.x; t < n_tracks; t += LGD_EPI_NT) {
-    const double *r = res + (size_t)t * LGR_STRIDE;
-    sr += r[LGR_ALB_SUM_REL];
-    nr += r[LGR_ALB_NREL];
-  }
-  sr = block_sum_f64<LGD_EPI_NT>(sr, sh);
-  nr = block_sum_f64<LGD_EPI_NT>(nr, sh);
-  if (threadIdx.x == 0) {
-    part2[0] = sr; part2[1] = nr;
-  }
-}
-
-// album[] = { loudness, lra(filled by lgd_lra_kernel), peak, thr, sum_abs, sum_rel, n_abs, n_rel, n_st }
-__global__ void lgd_album_final_kernel(const double *__restrict__ part1,
-                                       const double *__restrict__ part2, double rel_factor,
-                                       double *__restrict__ album) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double thr = 0.0;
-  if (part1[1] > 0.0) {
-    thr = part1[0] / part1[1];
-    thr *= rel_factor;
-  }
-  album[0] = part2[1] > 0.0 ? 10.0 * (log(part2[0] / part2[1]) / log(10.0)) - 0.691 : -HUGE_VAL;
-  album[2] = part1[2];
-  album[3] = thr;
-  album[4] = part1[0];
-  album[5] = part2[0];
-  album[6] = part1[1];
-  album[7] = part2[1];
-  album[8] = part1[3];
 }
 
 // ------------------------------------------------------- launch wrappers ---
@@ -649,43 +409,3 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, const LgdSeg *
   }
 }
 
-extern "C" hipError_t lgd_launch_track_epilogue(const LgdTrackMeta *meta, int n_tracks,
-                                                const double *E, double *st, const float *peaks,
-                                                double *res, double abs_gate, double rel_factor,
-                                                int do_tp, hipStream_t s) {
-  if (n_tracks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lgd_track_epilogue, dim3(n_tracks), dim3(LGD_EPI_NT), 0, s, meta, E, st, peaks,
-                     res, abs_gate, rel_factor, do_tp);
-  return hipGetLastError();
-}
-
-extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
-                                     double minus20, hipStream_t s) {
-  if (n_ranges <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lgd_lra_kernel, dim3(n_ranges), dim3(LGD_LRA_NT), 0, s,
-                     (const LgdRange *)ranges, st_base, minus20);
-  return hipGetLastError();
-}
-
-extern "C" hipError_t lgd_launch_album_part1(const double *res, int n_tracks, double *part1,
-                                             hipStream_t s) {
-  hipLaunchKernelGGL(lgd_album_part1_kernel, dim3(1), dim3(LGD_EPI_NT), 0, s, res, n_tracks, part1);
-  return hipGetLastError();
-}
-
-extern "C" hipError_t lgd_launch_album_stage2(const LgdTrackMeta *meta, int n_tracks,
-                                              const double *E, double *res, const double *part1,
-                                              double *part2, double abs_gate, double rel_factor,
-                                              hipStream_t s) {
-  if (n_tracks > 0)
-    hipLaunchKernelGGL(lgd_album_pass2_kernel, dim3(n_tracks), dim3(LGD_EPI_NT), 0, s, meta, E, res,
-                       part1, abs_gate, rel_factor);
-  hipLaunchKernelGGL(lgd_album_part2_kernel, dim3(1), dim3(LGD_EPI_NT), 0, s, res, n_tracks, part2);
-  return hipGetLastError();
-}
-
-extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *part2,
-                                             double rel_factor, double *album, hipStream_t s) {
-  hipLaunchKernelGGL(lgd_album_final_kernel, dim3(1), dim3(1), 0, s, part1, part2, rel_factor, album);
-  return hipGetLastError();
-}
