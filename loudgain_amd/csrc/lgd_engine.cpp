@@ -21,6 +21,7 @@
 #include "lgd_internal.h"
 
 extern "C" const int lgd_chunk_table[];
+extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp);
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
                                       const LgdFilt *F, hipStream_t s);
 extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_slices,
@@ -167,6 +168,7 @@ struct Group {  // tracks sharing (rate, channels) -> one scan launch
   LgdFilt F;
   size_t seg_begin, seg_count;
 };
+static const size_t MAX_GROUPS = 64;  // distinct (rate, channels) pairs per plan
 
 struct lgd_ctx {
   int device = 0;
@@ -181,11 +183,13 @@ struct lgd_ctx {
   std::vector<LgdRange> ranges;
   std::vector<LgdSlice> slices;
   std::vector<Group> groups;
-  uint64_t total_sb = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0, warm_bytes = 0;
+  uint64_t total_sb = 0, total_e = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0,
+           warm_bytes = 0;
   // device workspace
   double *d_E = nullptr, *d_Z = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
   double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr;  // per-slice gating partials
   LgdSlice *d_slices = nullptr;
+  LgdFilt *d_filt = nullptr;  // [MAX_GROUPS] per-group kernel constants
   double *d_part1 = nullptr, *d_part2 = nullptr;
   float *d_peaks = nullptr;
   LgdTrackMeta *d_meta = nullptr;
@@ -241,6 +245,7 @@ extern "C" lgd_ctx *lgd_create(int device) {
   ok = ok && hipMalloc((void **)&c->d_part1, 4 * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->d_part2, 2 * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->d_album_range, sizeof(LgdRange)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->d_filt, MAX_GROUPS * sizeof(LgdFilt)) == hipSuccess;
   ok = ok && hipHostMalloc((void **)&c->h_album_range, sizeof(LgdRange)) == hipSuccess;
   if (!ok) {
     fail(LGD_ENOMEM, "lgd_create: allocation failed");
@@ -255,7 +260,7 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
   (void)hipSetDevice(c->device);
   void *ptrs[] = {c->d_E, c->d_Z, c->d_st, c->d_res, c->d_album, c->d_part1, c->d_part2, c->d_peaks,
                   c->d_meta, c->d_segs, c->d_ranges, c->d_album_range, c->d_p1, c->d_p2, c->d_p2a,
-                  c->d_slices};
+                  c->d_slices, c->d_filt};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_album_range) (void)hipHostFree(c->h_album_range);
@@ -277,17 +282,25 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   return LGD_OK;
 }
 
-static int pick_chunk(long forced, int s100, unsigned nch) {
+static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
+  const size_t lds_cap = 160 * 1024;  // per CU == per workgroup limit on gfx950
   if (forced) {
     for (const int *p = lgd_chunk_table; *p; ++p)
-      if (*p == forced && s100 % *p == 0) return *p;
+      if (*p == forced && s100 % *p == 0 && lgd_scan_lds_bytes(*p, (int)nch, tp) <= lds_cap)
+        return *p;
     return 0;
   }
-  // preference: amortise the wave scan (large C) within the LDS/VGPR budget
-  static const int pref[] = {50, 49, 45, 35, 63, 25, 75, 0};
-  (void)nch;
-  for (const int *p = pref; *p; ++p)
-    if (s100 % *p == 0) return *p;
+  // preference: long chunks amortise the wave scan; the tile of all channels has
+  // to leave room for >= 2 workgroups per CU where possible
+  static const int pref_fast[] = {75, 63, 50, 49, 45, 35, 25, 0};
+  // the run-time-channel-count kernel is compiled for 16 waves (<= 128 VGPRs):
+  // short chunks keep its prefetch registers within that
+  static const int pref_many[] = {25, 35, 45, 49, 50, 63, 75, 0};
+  const int *pref = nch <= 2 ? pref_fast : pref_many;
+  for (int pass = 0; pass < 2; ++pass)
+    for (const int *p = pref; *p; ++p)
+      if (s100 % *p == 0 && lgd_scan_lds_bytes(*p, (int)nch, tp) <= (pass ? lds_cap : lds_cap / 4))
+        return *p;
   return 0;
 }
 
@@ -303,7 +316,7 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   c->ranges.clear();
   c->slices.clear();
   c->groups.clear();
-  c->total_sb = c->total_st = c->total_peak_floats = c->pcm_bytes = c->warm_bytes = 0;
+  c->total_sb = c->total_e = c->total_st = c->total_peak_floats = c->pcm_bytes = c->warm_bytes = 0;
 
   for (uint32_t t = 0; t < n; ++t) {
     const lgd_track &tr = tracks[t];
@@ -315,8 +328,8 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     if (tr.frames && !tr.pcm) return fail(LGD_EINVAL, "track %u: null PCM pointer", t);
     if (((uintptr_t)tr.pcm) & 15)
       return fail(LGD_EINVAL, "track %u: PCM pointer must be 16-byte aligned", t);
-    if (tr.channels > 2)
-      return fail(LGD_EUNSUP, "track %u: %u channels not covered by the kernels yet", t,
+    if (tr.channels > 16)
+      return fail(LGD_EUNSUP, "track %u: %u channels (the kernels cover 1..16 so far)", t,
                   tr.channels);
     LgdTrackMeta &m = c->meta[t];
     m.s100 = (int)((tr.rate + 5) / 10);
@@ -326,11 +339,13 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     m.n_sb = (int)nsb;
     m.n_st_slots = m.n_sb >= 30 ? (m.n_sb - 30) / 10 + 1 : 0;
     m.sb_off = (long long)c->total_sb;
+    m.e_off = (long long)c->total_e;
     m.st_off = (long long)c->total_st;
     m.slice_off = (int)c->slices.size();
     m.n_slices = m.n_sb >= 4 ? (m.n_sb - 3 + LGD_SLICE - 1) / LGD_SLICE : 0;
     for (int sl = 0; sl < m.n_slices; ++sl) c->slices.push_back(LgdSlice{(int)t, sl * LGD_SLICE});
     c->total_sb += nsb;
+    c->total_e += nsb * tr.channels;
     c->total_st += (uint64_t)m.n_st_slots;
     c->pcm_bytes += tr.frames * tr.channels * 4ull;
   }
@@ -340,9 +355,10 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   for (uint32_t t = 0; t < n; ++t) by_cfg[{tracks[t].rate, tracks[t].channels}].push_back(t);
 
   // segment length: spread all sub-blocks over ~waves_per_cu waves per CU
+  // (one wave per segment and channel: total_e counts sub-blocks x channels)
   const uint64_t target_waves = (uint64_t)c->n_cu * (uint64_t)c->p_waves_per_cu;
   uint64_t seg_sb = c->p_seg_sb ? (uint64_t)c->p_seg_sb
-                                : (c->total_sb + target_waves - 1) / (target_waves ? target_waves : 1);
+                                : (c->total_e + target_waves - 1) / (target_waves ? target_waves : 1);
   const uint64_t min_seg = (uint64_t)std::max<long>(4, 3 * c->p_warm_sb);
   if (!c->p_seg_sb && seg_sb < min_seg) seg_sb = min_seg;  // keep the warm-up overhead bounded
   if (seg_sb < 1) seg_sb = 1;
@@ -352,16 +368,19 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     g.rate = kv.first.first;
     g.nch = kv.first.second;
     const int s100 = (int)((g.rate + 5) / 10);
-    g.chunk = pick_chunk(c->p_chunk, s100, g.nch);
-    if (!g.chunk)
-      return fail(LGD_EUNSUP, "no compiled chunk length divides the %d-frame sub-block of %u Hz",
-                  s100, g.rate);
     g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
+    g.chunk = pick_chunk(c->p_chunk, s100, g.nch, g.tp);
+    if (!g.chunk)
+      return fail(LGD_EUNSUP,
+                  "no compiled chunk length divides the %d-frame sub-block of %u Hz and fits LDS "
+                  "with %u channels", s100, g.rate, g.nch);
     memset(&g.F, 0, sizeof(g.F));
     design_kfilter((double)g.rate, g.F.pb, g.F.pa, g.F.ra);
     design_scan_basis(g.F, g.chunk);
     design_interp(g.tp, g.F.tp);
-    g.F.w[0] = g.F.w[1] = 1.0f;  // L, R (mono is NOT dual-mono: weight 1.0)
+    g.F.pbn[0] = g.F.pb[1] / g.F.pb[0];
+    g.F.pbn[1] = g.F.pb[2] / g.F.pb[0];
+    g.F.pb0sq = g.F.pb[0] * g.F.pb[0];
     g.F.lps = s100 / g.chunk;
     g.seg_begin = c->segs.size();
     const long long tile_f = 64LL * g.chunk;
@@ -386,7 +405,9 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
         sg.f_peak_end = (s + 1 == nseg) ? (long long)tr.frames : (long long)((sb0 + cnt) * s100);
         sg.n_warm_tiles = sb0 ? warm_tiles : 0;
         // offsets are patched to pointers once the workspace exists
-        sg.e_out = (double *)(uintptr_t)(m.sb_off + (long long)sb0);
+        sg.e_out = (double *)(uintptr_t)(m.e_off + (long long)sb0);
+        sg.e_ch_stride = m.n_sb;
+        sg.pad = 0;
         sg.peak_out = (float *)(uintptr_t)(m.peak_off + (long long)(s * 2ull * tr.channels));
         c->segs.push_back(sg);
         if (sb0) c->warm_bytes += (uint64_t)warm_tiles * tile_f * tr.channels * 4ull;
@@ -398,7 +419,7 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   }
 
   int rc;
-  if ((rc = ensure(&c->d_E, &c->cap_E, c->total_sb))) return rc;
+  if ((rc = ensure(&c->d_E, &c->cap_E, c->total_e))) return rc;
   if ((rc = ensure(&c->d_Z, &c->cap_Z, c->total_sb))) return rc;
   if ((rc = ensure(&c->d_p1, &c->cap_p1, 4 * c->slices.size()))) return rc;
   if ((rc = ensure(&c->d_p2, &c->cap_p2, 2 * c->slices.size()))) return rc;
@@ -431,6 +452,10 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   if (!c->slices.empty())
     HIPCHK(hipMemcpy(c->d_slices, c->slices.data(), c->slices.size() * sizeof(LgdSlice),
                      hipMemcpyHostToDevice));
+  if (c->groups.size() > MAX_GROUPS)
+    return fail(LGD_EUNSUP, "more than %zu distinct (rate, channels) pairs in one plan", MAX_GROUPS);
+  for (size_t gi = 0; gi < c->groups.size(); ++gi)
+    HIPCHK(hipMemcpy(c->d_filt + gi, &c->groups[gi].F, sizeof(LgdFilt), hipMemcpyHostToDevice));
   c->planned = true;
   return LGD_OK;
 }
@@ -465,9 +490,11 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   c->last_stream = s;
   hipEvent_t *ev = c->ev[c->n_exec % lgd_ctx::EV_RING];
   HIPCHK(hipEventRecord(ev[0], s));
-  for (const Group &g : c->groups)
+  for (size_t gi = 0; gi < c->groups.size(); ++gi) {
+    const Group &g = c->groups[gi];
     HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, c->d_segs + g.seg_begin, (int)g.seg_count,
-                           &g.F, s));
+                           c->d_filt + gi, s));
+  }
   HIPCHK(hipEventRecord(ev[1], s));
   HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, c->d_E, c->d_Z,
                                    c->d_st, c->d_peaks, c->d_p1, c->d_p2, c->d_res, c->abs_gate,
@@ -556,8 +583,20 @@ extern "C" int lgd_copy_subblock_energies(lgd_ctx *c, uint32_t track, double *ho
   const LgdTrackMeta &m = c->meta[track];
   const uint64_t n = std::min<uint64_t>(cap, (uint64_t)m.n_sb);
   if (n_out) *n_out = (uint64_t)m.n_sb;
-  if (n && host_out)
-    HIPCHK(hipMemcpy(host_out, c->d_E + m.sb_off, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (n && host_out) {
+    // weighted channel sum, as the gating kernel forms it
+    std::vector<double> tmp((size_t)m.n_sb * m.nch);
+    HIPCHK(hipMemcpy(tmp.data(), c->d_E + m.e_off, tmp.size() * sizeof(double),
+                     hipMemcpyDeviceToHost));
+    for (uint64_t j = 0; j < n; ++j) {
+      double s = 0.0;
+      for (int ch = 0; ch < m.nch; ++ch) {
+        const double w = lgd_channel_weight(ch, m.nch);
+        if (w != 0.0) s += w * tmp[(size_t)ch * m.n_sb + j];
+      }
+      host_out[j] = s;
+    }
+  }
   return LGD_OK;
 }
 

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
   const LgdSlice sl = slices[blockIdx.x];
   const LgdTrackMeta m = meta[sl.track];
-  const double *E = E_all + m.sb_off;
+  const double *E = E_all + m.e_off;  // channel ch, sub-block j at E[ch * n_sb + j]
   double *Z = Z_all + m.sb_off;
   const int tid = threadIdx.x;
   const int nblk = m.n_sb - 3;
@@ -72,8 +72,19 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
   // divide like the reference does (sum /= frames_per_block), not by a reciprocal
   const double len4 = 4.0 * (double)m.s100, len30 = 30.0 * (double)m.s100;
   double cnt = 0.0, sum = 0.0, cst = 0.0;
+  // block energy = sum_c w_c * (channel sum over the block) / frames (A.4);
+  // channels mapped EBUR128_UNUSED (weight 0) are skipped like the reference does
   for (int j = sl.j0 + tid; j < j1; j += LGD_EPI_NT) {
-    const double zj = (((E[j] + E[j + 1]) + E[j + 2]) + E[j + 3]) / len4;
+    double s = 0.0;
+    for (int ch = 0; ch < m.nch; ++ch) {
+      const double w = lgd_channel_weight(ch, m.nch);
+      if (w == 0.0) continue;
+      const double *Ec = E + (size_t)ch * m.n_sb + j;
+      double cs = ((Ec[0] + Ec[1]) + Ec[2]) + Ec[3];
+      if (w != 1.0) cs *= w;
+      s += cs;
+    }
+    const double zj = s / len4;
     Z[j] = zj;
     if (zj >= abs_gate) { cnt += 1.0; sum += zj; }
   }
@@ -81,10 +92,17 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
   // that holds 400 ms block 10 kk
   const int k0 = (sl.j0 + 9) / 10, k1 = min((sl.j0 + LGD_SLICE + 9) / 10, m.n_st_slots);
   for (int kk = k0 + tid; kk < k1; kk += LGD_EPI_NT) {
-    const double *p = E + 10 * kk;
     double s = 0.0;
+    for (int ch = 0; ch < m.nch; ++ch) {
+      const double w = lgd_channel_weight(ch, m.nch);
+      if (w == 0.0) continue;
+      const double *p = E + (size_t)ch * m.n_sb + 10 * kk;
+      double cs = 0.0;
 #pragma unroll 6
-    for (int i = 0; i < 30; ++i) s += p[i];
+      for (int i = 0; i < 30; ++i) cs += p[i];
+      if (w != 1.0) cs *= w;
+      s += cs;
+    }
     s /= len30;
     const bool listed = s >= abs_gate;
     st_all[m.st_off + kk] = listed ? s : 0.0;  // 0.0 == not listed

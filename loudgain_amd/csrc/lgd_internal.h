@@ -11,10 +11,13 @@ struct LgdSeg {
   long long n_floats;    // frames * channels of the whole track
   long long f0;          // first frame of this segment (multiple of s100)
   long long f_peak_end;  // tiles cover [f0, f_peak_end)
-  double *e_out;         // sub-block energies of this segment, n_sb slots
+  double *e_out;         // sub-block energies of this segment: channel ch at
+                         // e_out[ch * e_ch_stride + 0 .. n_sb) (unweighted sum y^2)
   float *peak_out;       // [2][nch]: sample peaks, then interpolated peaks
   int n_sb;              // whole sub-blocks in this segment
   int n_warm_tiles;      // K-filter warm-up tiles run before f0 (0 at track start)
+  int e_ch_stride;       // whole sub-blocks of the track (channel stride in E)
+  int pad;
 };
 
 // Per-(rate, chunk) constants, passed by value as a kernel argument.
@@ -24,13 +27,14 @@ struct LgdFilt {
   double ra[2];      // RLB denominator a1, a2
   double pa[2];      // shelf denominator a1, a2
   double pb[3];      // shelf numerator
+  double pbn[2];     // pb1/pb0, pb2/pb0: the kernel forms y/pb0 ...
+  double pb0sq;      // ... and scales each 100 ms sum by pb0^2
   double alpha, beta, inv_alpha, inv_beta;  // slope coordinate of the RLB pole pair
   double gamma, dc;  // shelf-state scaling (dc = 1 / (1 + pa1 + pa2))
   double g[2][4];    // effect of w[0], w[1] of a chunk on its end state (scan basis)
   double P[6][16];   // transition over C * 2^j frames, j = 0..5 (scan basis, row-major;
                      // block lower triangular: P[.][2], [3], [6], [7] are zero)
   float tp[36];      // 4x: phases 1..3 x 12 taps; 2x: phase 1 x 24 taps (A.5)
-  float w[2];        // channel weights of the 1/2-channel fast path
   int lps;           // lanes (C-frame chunks) per 100 ms sub-block = s100 / C
   int pad;
 };
@@ -46,8 +50,9 @@ struct LgdSlice {
 };
 
 struct LgdTrackMeta {
-  long long sb_off;   // first slot of this track in the sub-block energy array
-                      // (and of its 400 ms block energies in the Z array)
+  long long e_off;    // first slot of this track in the sub-block energy array E:
+                      // channel ch, sub-block j at E[e_off + ch * n_sb + j]
+  long long sb_off;   // first slot of its 400 ms block energies in the Z array
   long long st_off;   // first slot in the short-term energy array
   long long peak_off; // first float of this track's [n_seg][2][nch] peak partials
   int n_sb;           // whole sub-blocks
@@ -66,6 +71,21 @@ struct LgdRange {
   long long n;
   double *out;
 };
+
+// libebur128's default channel map by index: weight of channel
+// `ch` of an `nch`-channel stream; 0 = EBUR128_UNUSED (peaks only, e.g. LFE).
+#if defined(__HIPCC__)
+#define LGD_HD __host__ __device__
+#else
+#define LGD_HD
+#endif
+static inline LGD_HD double lgd_channel_weight(int ch, int nch) {
+  if (nch == 4) return ch < 2 ? 1.0 : 1.41;
+  if (nch == 5) return ch < 3 ? 1.0 : 1.41;
+  if (ch < 3) return 1.0;
+  if (ch == 4 || ch == 5) return 1.41;
+  return 0.0;
+}
 
 // per-track device result: 16 doubles (counts are integer-valued doubles)
 enum {

@@ -7,7 +7,7 @@
 // (the gating / LRA / album epilogue kernels live in lgd_epilogue.hip)
 //
 // Parallelisation of the strictly sequential IIR:
-// one wavefront owns a run of whole 100 ms sub-blocks.  It walks that run in
+// one wavefront owns one channel of a run of whole 100 ms sub-blocks.  It walks that run in
 // tiles of 64 lanes x C frames; inside a tile every lane
 //   A. runs the 4th-order recurrence from a ZERO state over its C frames
 //      (gives the zero-state final state z_lane),
@@ -59,70 +59,90 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 }
 
 // ------------------------------------------------------------ scan kernel ---
+// One workgroup per segment, one WAVEFRONT PER CHANNEL: the nch waves of a
+// workgroup stage one interleaved tile in LDS together and each filters its own
+// channel (so registers and LDS per wave do not grow with the channel count, and
+// any channel count up to 16 runs the same code).
 // C   frames per lane (divides the 100 ms sub-block length of the rate)
-// NCH 1 or 2 interleaved channels, both weight 1.0 (L / L,R)
+// G   channels == waves per workgroup; 0 = run-time value (frame stride in LDS
+//     is then a register instead of an immediate)
 // TP  0 = no interpolator (>= 192 kHz or disabled), 4 = 4x, 2 = 2x
-template <int C, int NCH, int TP>
+template <int C, int TP>
 struct ScanCfg {
   static constexpr int HALO = (TP == 2) ? 24 : 12;     // frames kept before the tile
   static constexpr int NTAP = (TP == 2) ? 24 : 12;     // taps per non-trivial phase
   static constexpr int NPH = (TP == 4) ? 3 : (TP == 2 ? 1 : 0);
+  static constexpr int HX = (TP == 0) ? 0 : (NTAP - 1);  // history frames the FIR needs
   static constexpr int TILE_F = LGD_WAVE * C;
-  static constexpr int LDS_FLOATS = (TILE_F + HALO) * NCH + 4;
-  static constexpr int NVEC = LDS_FLOATS / 4;
+  // 16-B vectors per thread and tile: ceil(((TILE_F + HALO) nch + 4) / 4 / (64 nch))
+  static constexpr int NV = (16 * C + HALO / 4 + 1 + 63) / 64;
   // frames per streamed step: the largest divisor of C not above 8
   static constexpr int U = (C % 8 == 0) ? 8 : (C % 7 == 0) ? 7 : (C % 6 == 0) ? 6 : (C % 5 == 0) ? 5
                          : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : (C % 2 == 0) ? 2 : 1;
 };
 
-template <int C, int NCH, int TP>
-__global__ __launch_bounds__(LGD_WAVE) void lgd_scan_kernel(const LgdSeg *__restrict__ segs,
-                                                           const LgdFilt F) {
-  using K = ScanCfg<C, NCH, TP>;
-  __shared__ __attribute__((aligned(16))) float lds[K::LDS_FLOATS];
+// (launch bounds: G waves per workgroup, >= 2 waves per SIMD wanted -> <= 256 VGPRs;
+// the run-time-G variant must fit 16 waves -> <= 128 VGPRs, so the host gives it
+// short chunks)
+template <int C, int G, int TP>
+__global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_kernel(
+    const LgdSeg *__restrict__ segs, const LgdFilt *__restrict__ Fg, const int nch_rt) {
+  using K = ScanCfg<C, TP>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
 
-  const int lane = threadIdx.x;
+  // the per-(rate, chunk) constants live in constant memory: uniform loads from
+  // this address space are scalar loads (s_load), so the 72 doubles of scan
+  // matrices are fetched per tile instead of occupying (and spilling) SGPRs
+  typedef const LgdFilt __attribute__((address_space(4))) *cfilt_ptr;
+  const cfilt_ptr F0 = (cfilt_ptr)Fg;
+#define F (*F0)
+  const int nch = G ? G : nch_rt;          // channels == waves in this workgroup
+  const int tid = threadIdx.x;
+  const int lane = tid & (LGD_WAVE - 1);
+  // this wave's channel, as a scalar so that channel-dependent branches are uniform
+  const int ch = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = LGD_WAVE * nch;
   const LgdSeg sg = segs[blockIdx.x];
-  const int shift = (int)((sg.f0 * NCH) & 3);
-  const long long n_frames = sg.n_floats / NCH;
+  const int shift = (int)((sg.f0 * nch) & 3);
+  const long long n_frames = sg.n_floats / nch;
+  const int nvec = ((K::TILE_F + K::HALO) * nch + 4) >> 2;  // 16-B vectors per tile
+  const bool filt = lgd_channel_weight(ch, nch) > 0.0;       // wave-uniform
 
   const double ra1 = F.ra[0], ra2 = F.ra[1], pa1 = F.pa[0], pa2 = F.pa[1];
-  const double pb0 = F.pb[0], pb1 = F.pb[1], pb2 = F.pb[2];
-
-  double cin[NCH][4];  // wave-uniform filter state entering the tile
+  const double c1 = F.pbn[0], c2 = F.pbn[1];
+  const double alpha = F.alpha, beta = F.beta, gamma_ = F.gamma, inv_alpha = F.inv_alpha,
+               inv_beta = F.inv_beta, dcg = F.dc, pb0sq = F.pb0sq;
+  const int lps = F.lps;
+  float tpc[K::NPH * K::NTAP + 1];
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) cin[ch][r] = 0.0;
+  for (int i = 0; i < K::NPH * K::NTAP; ++i) tpc[i] = F.tp[i];
 
+  double cin[4] = {0.0, 0.0, 0.0, 0.0};  // wave-uniform filter state entering the tile
   double acc = 0.0;       // this lane's share of sub-block `cur`
   int cur = 0;            // sub-block (relative to the segment) being summed
   long long cur_q = 0;    // chunk index (relative to f0) where `cur` starts
-  float pk_s[NCH], pk_t[NCH];
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) pk_s[ch] = pk_t[ch] = 0.f;
+  float pk_s = 0.f, pk_t = 0.f;
 
   const int n_main = (int)((sg.f_peak_end - sg.f0 + K::TILE_F - 1) / K::TILE_F);
 
   // ---- tile staging: coalesced 16-B loads -> registers -> LDS.  The NEXT tile's
   // loads are issued before the current tile is computed (software prefetch,
-  // NV float4 per lane in flight); tiles touching a track edge take the guarded
+  // NV x 16 B per lane in flight); tiles touching a track edge take the guarded
   // path, where frames outside [0, n_frames) read as zero.
-  constexpr int NV = (K::NVEC + LGD_WAVE - 1) / LGD_WAVE;
-  f32x4 pf[NV];
+  f32x4 pf[K::NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) pf[i] = (f32x4)(0.f);
+  for (int i = 0; i < K::NV; ++i) pf[i] = (f32x4)(0.f);
   bool pf_valid = false;
-#define LGD_TILE_G0(kk) ((sg.f0 + (long long)(kk) * K::TILE_F - K::HALO) * NCH - shift)
+#define LGD_TILE_G0(kk) ((sg.f0 + (long long)(kk) * K::TILE_F - K::HALO) * nch - shift)
 #define LGD_PREFETCH(kk)                                                                \
   do {                                                                                  \
     const long long g0_ = LGD_TILE_G0(kk); /* float index of lds[0], multiple of 4 */   \
-    pf_valid = (g0_ >= 0) && (g0_ + 4LL * K::NVEC <= sg.n_floats); /* wave-uniform */   \
+    pf_valid = (g0_ >= 0) && (g0_ + 4LL * nvec <= sg.n_floats); /* block-uniform */     \
     if (pf_valid) {                                                                     \
       const gvec_ptr src_ = (gvec_ptr)(sg.pcm + g0_);                                   \
-      _Pragma("unroll") for (int i_ = 0; i_ < NV; ++i_) {                               \
-        const int idx_ = lane + LGD_WAVE * i_;                                          \
-        if (i_ + 1 < NV || idx_ < K::NVEC) pf[i_] = src_[idx_];                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < K::NV; ++i_) {                            \
+        const int idx_ = tid + nthreads * i_;                                           \
+        if (idx_ < nvec) pf[i_] = src_[idx_];                                           \
       }                                                                                 \
     }                                                                                   \
   } while (0)
@@ -130,18 +150,18 @@ __global__ __launch_bounds__(LGD_WAVE) void lgd_scan_kernel(const LgdSeg *__rest
 
   for (int k = -sg.n_warm_tiles; k < n_main; ++k) {
     const long long tb = sg.f0 + (long long)k * K::TILE_F;  // first frame of the tile
-    __syncthreads();  // previous tile's LDS reads are done
+    __syncthreads();  // every wave is done reading the previous tile
     if (pf_valid) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int idx = lane + LGD_WAVE * i;
-        if (i + 1 < NV || idx < K::NVEC) *reinterpret_cast<f32x4 *>(lds + 4 * idx) = pf[i];
+      for (int i = 0; i < K::NV; ++i) {
+        const int idx = tid + nthreads * i;
+        if (idx < nvec) *reinterpret_cast<f32x4 *>(lds + 4 * idx) = pf[i];
       }
     } else {
       const long long g0 = LGD_TILE_G0(k);
-      for (int i = lane; i < K::NVEC; i += LGD_WAVE) {
+      const gflt_ptr gp = (gflt_ptr)sg.pcm;
+      for (int i = tid; i < nvec; i += nthreads) {
         const long long g = g0 + 4LL * i;
-        const gflt_ptr gp = (gflt_ptr)sg.pcm;
         f32x4 v;
         if (g >= 0 && g + 3 < sg.n_floats) {
           v = *(gvec_ptr)(sg.pcm + g);
@@ -157,118 +177,93 @@ __global__ __launch_bounds__(LGD_WAVE) void lgd_scan_kernel(const LgdSeg *__rest
     __syncthreads();
     if (k + 1 < n_main) LGD_PREFETCH(k + 1); else pf_valid = false;
 
-    // this lane's chunk: frames [tb + lane*C, +C), streamed from LDS U frames at a
-    // time (keeps the VGPR count low; LDS reads are ~free next to the fp64 work)
+    // this lane's chunk of this wave's channel: frames [tb + lane*C, +C), frame
+    // stride nch floats, streamed from LDS U frames at a time
     constexpr int U = K::U;
-    constexpr int HX = (TP == 0) ? 0 : (K::NTAP - 1);
-    const float *chunk = lds + shift + (K::HALO + lane * C) * NCH;
+    constexpr int HX = K::HX;
+    const float *chunk = lds + shift + (K::HALO + lane * C) * nch + ch;
+#define LGD_X(j) chunk[(j) * (G ? G : nch)]
 
-    // ---- A: zero-state run of q' = x/ra, p' = q'/pa over the chunk (4 FMAs per
-    // sample).  (1 - z^-1)^2 commutes with both, so second differences of the
-    // last four q', p' give the zero-state (q, p) at the chunk end; q', p' stay
-    // <= ~C^2 |x| here, so the differencing costs ~1e-13 |x| at most. --------
-    double z[NCH][4];
-    {
-      double qv[NCH][4], pv[NCH][4];
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) qv[ch][r] = pv[ch][r] = 0.0;
+    // per-tile opaque copy of the constants pointer: keeps the scan-matrix loads
+    // inside the tile loop (scalar cache hits) instead of hoisted into SGPRs
+    cfilt_ptr Fk = F0;
+    asm volatile("" : "+s"(Fk));
+    double qs[2] = {0.0, 0.0}, ps[2] = {0.0, 0.0};
+    if (filt) {
+      // ---- A: zero-state run of q' = x/ra, p' = q'/pa over the chunk (4 FMAs per
+      // sample).  (1 - z^-1)^2 commutes with both, so second differences of the
+      // last four q', p' give the zero-state (q, p) at the chunk end; q', p' stay
+      // <= ~C^2 |x| here, so the differencing costs ~1e-13 |x| at most. --------
+      double z[4];
+      {
+        double qv[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
-      for (int j0 = 0; j0 < C; j0 += U) {
-        float xa[NCH][U];
+        for (int j0 = 0; j0 < C; j0 += U) {
+          float xa[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if constexpr (NCH == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(chunk + 2 * (j0 + u));
-            xa[0][u] = t.x;
-            xa[1][u] = t.y;
-          } else {
-            xa[0][u] = chunk[j0 + u];
+          for (int u = 0; u < U; ++u) xa[u] = LGD_X(j0 + u);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            double t = fma(-ra2, qv[1], (double)xa[u]);
+            const double q0 = fma(-ra1, qv[0], t);
+            t = fma(-pa2, pv[1], q0);
+            const double p0 = fma(-pa1, pv[0], t);
+            qv[3] = qv[2]; qv[2] = qv[1]; qv[1] = qv[0]; qv[0] = q0;
+            pv[3] = pv[2]; pv[2] = pv[1]; pv[1] = pv[0]; pv[0] = p0;
           }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) {
-            double t = fma(-ra2, qv[ch][1], (double)xa[ch][u]);
-            const double q0 = fma(-ra1, qv[ch][0], t);
-            t = fma(-pa2, pv[ch][1], q0);
-            const double p0 = fma(-pa1, pv[ch][0], t);
-            qv[ch][3] = qv[ch][2]; qv[ch][2] = qv[ch][1]; qv[ch][1] = qv[ch][0]; qv[ch][0] = q0;
-            pv[ch][3] = pv[ch][2]; pv[ch][2] = pv[ch][1]; pv[ch][1] = pv[ch][0]; pv[ch][0] = p0;
-          }
-      }
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch) {
-        const double q1 = (qv[ch][0] - 2.0 * qv[ch][1]) + qv[ch][2];
-        const double q2 = (qv[ch][1] - 2.0 * qv[ch][2]) + qv[ch][3];
-        const double p1 = (pv[ch][0] - 2.0 * pv[ch][1]) + pv[ch][2];
-        const double p2 = (pv[ch][1] - 2.0 * pv[ch][2]) + pv[ch][3];
+        const double q1 = (qv[0] - 2.0 * qv[1]) + qv[2];
+        const double q2 = (qv[1] - 2.0 * qv[2]) + qv[3];
+        const double p1 = (pv[0] - 2.0 * pv[1]) + pv[2];
+        const double p2 = (pv[1] - 2.0 * pv[2]) + pv[3];
         // the run assumed x[-1] = x[-2] = 0; the true history changes w[0] by
         // -2x[-1] + x[-2] and w[1] by x[-1] (g = their effect on the end state)
-        const double xm1 = (double)chunk[-1 * NCH + ch], xm2 = (double)chunk[-2 * NCH + ch];
+        const double xm1 = (double)LGD_X(-1), xm2 = (double)LGD_X(-2);
         const double dw0 = fma(-2.0, xm1, xm2), dw1 = xm1;
-        double s0 = q1, s1 = F.alpha * fma(-F.beta, q2, q1), s2 = F.gamma * p1, s3 = F.gamma * p2;
-        s0 = fma(F.g[0][0], dw0, s0); s0 = fma(F.g[1][0], dw1, s0);
-        s1 = fma(F.g[0][1], dw0, s1); s1 = fma(F.g[1][1], dw1, s1);
-        s2 = fma(F.g[0][2], dw0, s2); s2 = fma(F.g[1][2], dw1, s2);
-        s3 = fma(F.g[0][3], dw0, s3); s3 = fma(F.g[1][3], dw1, s3);
-        z[ch][0] = s0; z[ch][1] = s1; z[ch][2] = s2; z[ch][3] = s3;
+        double s0 = q1, s1 = alpha * fma(-beta, q2, q1), s2 = gamma_ * p1, s3 = gamma_ * p2;
+        s0 = fma(Fk->g[0][0], dw0, s0); s0 = fma(Fk->g[1][0], dw1, s0);
+        s1 = fma(Fk->g[0][1], dw0, s1); s1 = fma(Fk->g[1][1], dw1, s1);
+        s2 = fma(Fk->g[0][2], dw0, s2); s2 = fma(Fk->g[1][2], dw1, s2);
+        s3 = fma(Fk->g[0][3], dw0, s3); s3 = fma(Fk->g[1][3], dw1, s3);
+        z[0] = s0; z[1] = s1; z[2] = s2; z[3] = s3;
       }
-    }
 
-    // ---- B: inject the carry at lane 0, then Kogge-Stone over 64 lanes.  The
-    // transition is block lower triangular: rows 0,1 see columns 0,1 only. ----
+      // ---- B: inject the carry at lane 0, then Kogge-Stone over 64 lanes.  The
+      // transition is block lower triangular: rows 0,1 see columns 0,1 only. ----
+      if (lane == 0) {
+        const auto *P = Fk->P[0];
+        z[0] += fma(P[1], cin[1], P[0] * cin[0]);
+        z[1] += fma(P[5], cin[1], P[4] * cin[0]);
+        z[2] += fma(P[11], cin[3], fma(P[10], cin[2], fma(P[9], cin[1], P[8] * cin[0])));
+        z[3] += fma(P[15], cin[3], fma(P[14], cin[2], fma(P[13], cin[1], P[12] * cin[0])));
+      }
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const double *P = F.P[0];
-      const double t0 = fma(P[1], cin[ch][1], P[0] * cin[ch][0]);
-      const double t1 = fma(P[5], cin[ch][1], P[4] * cin[ch][0]);
-      const double t2 = fma(P[11], cin[ch][3], fma(P[10], cin[ch][2], fma(P[9], cin[ch][1], P[8] * cin[ch][0])));
-      const double t3 = fma(P[15], cin[ch][3], fma(P[14], cin[ch][2], fma(P[13], cin[ch][1], P[12] * cin[ch][0])));
-      const bool l0 = lane == 0;
-      z[ch][0] += l0 ? t0 : 0.0;
-      z[ch][1] += l0 ? t1 : 0.0;
-      z[ch][2] += l0 ? t2 : 0.0;
-      z[ch][3] += l0 ? t3 : 0.0;
-    }
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      const int d = 1 << s;
-      const double *P = F.P[s];
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch) {
+      for (int s = 0; s < 6; ++s) {
+        const int d = 1 << s;
+        const auto *P = Fk->P[s];
         double u[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) u[c] = __shfl_up(z[ch][c], d, LGD_WAVE);
-        const bool on = lane >= d;
-        const double t0 = fma(P[1], u[1], P[0] * u[0]);
-        const double t1 = fma(P[5], u[1], P[4] * u[0]);
-        const double t2 = fma(P[11], u[3], fma(P[10], u[2], fma(P[9], u[1], P[8] * u[0])));
-        const double t3 = fma(P[15], u[3], fma(P[14], u[2], fma(P[13], u[1], P[12] * u[0])));
-        z[ch][0] += on ? t0 : 0.0;
-        z[ch][1] += on ? t1 : 0.0;
-        z[ch][2] += on ? t2 : 0.0;
-        z[ch][3] += on ? t3 : 0.0;
+        for (int c = 0; c < 4; ++c) u[c] = __shfl_up(z[c], d, LGD_WAVE);
+        if (lane >= d) {  // exec-masked, no cross-lane traffic inside
+          z[0] += fma(P[1], u[1], P[0] * u[0]);
+          z[1] += fma(P[5], u[1], P[4] * u[0]);
+          z[2] += fma(P[11], u[3], fma(P[10], u[2], fma(P[9], u[1], P[8] * u[0])));
+          z[3] += fma(P[15], u[3], fma(P[14], u[2], fma(P[13], u[1], P[12] * u[0])));
+        }
       }
-    }
-    // z is now the exact state at the END of each lane's chunk; the state at
-    // its START is the previous lane's (lane 0: the carry).  Back to (q, p).
-    double qs[NCH][2], ps[NCH][2];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
+      // z is now the exact state at the END of each lane's chunk; the state at
+      // its START is the previous lane's (lane 0: the carry).  Back to (q, p).
       double sv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double up = __shfl_up(z[ch][r], 1, LGD_WAVE);
-        sv[r] = (lane == 0) ? cin[ch][r] : up;
-        cin[ch][r] = __shfl(z[ch][r], LGD_WAVE - 1, LGD_WAVE);
+        const double up = __shfl_up(z[r], 1, LGD_WAVE);
+        sv[r] = (lane == 0) ? cin[r] : up;
+        cin[r] = __shfl(z[r], LGD_WAVE - 1, LGD_WAVE);
       }
-      qs[ch][0] = sv[0];
-      qs[ch][1] = fma(-F.inv_alpha, sv[1], sv[0]) * F.inv_beta;
-      ps[ch][0] = sv[2] * F.dc;
-      ps[ch][1] = sv[3] * F.dc;
+      qs[0] = sv[0];
+      qs[1] = fma(-inv_alpha, sv[1], sv[0]) * inv_beta;
+      ps[0] = sv[2] * dcg;
+      ps[1] = sv[3] * dcg;
     }
 
     if (k < 0) continue;  // warm-up tile: only the carry matters
@@ -277,135 +272,154 @@ __global__ __launch_bounds__(LGD_WAVE) void lgd_scan_kernel(const LgdSeg *__rest
     // frames >= n_frames were staged as zeros; their interpolator outputs do
     // not exist in the reference (it stops at the last input frame)
     const long long lane_f = tb + (long long)lane * C;
-    const bool tail = (tb + K::TILE_F > n_frames);  // wave-uniform
+    const bool tail = (tb + K::TILE_F > n_frames);  // block-uniform
     int nvalid = C;
     if (tail) {
       const long long rem = n_frames - lane_f;
       nvalid = rem < 0 ? 0 : (rem > C ? C : (int)rem);
     }
-    double ech[NCH], xh[NCH][2];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      ech[ch] = 0.0;
-      xh[ch][0] = (double)chunk[-1 * NCH + ch];
-      xh[ch][1] = (double)chunk[-2 * NCH + ch];
-    }
+    double e = 0.0;
+    // sample peak + (optionally) the polyphase interpolator of one window
+#define LGD_PEAKS(u_)                                                                   \
+    do {                                                                                \
+      pk_s = fmaxf(pk_s, fabsf(w[HX + (u_)]));                                          \
+      if constexpr (TP != 0) {                                                          \
+        float m_ = 0.f;                                                                 \
+        _Pragma("unroll") for (int ph = 0; ph < K::NPH; ++ph) {                         \
+          float o_ = 0.f;                                                               \
+          _Pragma("unroll") for (int t2 = 0; t2 < K::NTAP; ++t2)                        \
+            o_ = fmaf(tpc[ph * K::NTAP + t2], w[HX + (u_) - t2], o_);                   \
+          m_ = fmaxf(m_, fabsf(o_));                                                    \
+        }                                                                               \
+        if (tail) m_ = (j0 + (u_) < nvalid) ? m_ : 0.f;                                 \
+        pk_t = fmaxf(pk_t, m_);                                                         \
+      }                                                                                 \
+    } while (0)
+    if (filt) {
+      double xh0 = (double)LGD_X(-1), xh1 = (double)LGD_X(-2);
 #pragma unroll 1
-    for (int j0 = 0; j0 < C; j0 += U) {
-      float w[NCH][U + HX];  // frames j0-HX .. j0+U-1
+      for (int j0 = 0; j0 < C; j0 += U) {
+        float w[U + HX];  // frames j0-HX .. j0+U-1
 #pragma unroll
-      for (int i = 0; i < U + HX; ++i) {
-        if constexpr (NCH == 2) {
-          const float2 t = *reinterpret_cast<const float2 *>(chunk + 2 * (j0 + i - HX));
-          w[0][i] = t.x;
-          w[1][i] = t.y;
-        } else {
-          w[0][i] = chunk[j0 + i - HX];
+        for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double x = (double)w[HX + u];
+          double t = fma(-2.0, xh0, x) + xh1;  // w[n], exact
+          xh1 = xh0;
+          xh0 = x;
+          t = fma(-ra2, qs[1], t);
+          const double q0 = fma(-ra1, qs[0], t);
+          t = fma(-pa2, ps[1], q0);
+          const double p0 = fma(-pa1, ps[0], t);
+          // y / pb0 = p0 + (pb1/pb0) p1 + (pb2/pb0) p2; pb0^2 is applied per sub-block
+          const double y = fma(c2, ps[1], fma(c1, ps[0], p0));
+          e = fma(y, y, e);
+          qs[1] = qs[0]; qs[0] = q0;
+          ps[1] = ps[0]; ps[0] = p0;
+          LGD_PEAKS(u);
         }
       }
+    } else {
+      // channel mapped EBUR128_UNUSED (e.g. LFE): no loudness, peaks only
+#pragma unroll 1
+      for (int j0 = 0; j0 < C; j0 += U) {
+        float w[U + HX];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+        for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-          const float xf = w[ch][HX + u];
-          const double x = (double)xf;
-          double t = fma(-2.0, xh[ch][0], x) + xh[ch][1];  // w[n], exact
-          xh[ch][1] = xh[ch][0];
-          xh[ch][0] = x;
-          t = fma(-ra2, qs[ch][1], t);
-          const double q0 = fma(-ra1, qs[ch][0], t);
-          t = fma(-pa2, ps[ch][1], q0);
-          const double p0 = fma(-pa1, ps[ch][0], t);
-          double y = pb0 * p0;
-          y = fma(pb1, ps[ch][0], y);
-          y = fma(pb2, ps[ch][1], y);
-          ech[ch] = fma(y, y, ech[ch]);
-          qs[ch][1] = qs[ch][0]; qs[ch][0] = q0;
-          ps[ch][1] = ps[ch][0]; ps[ch][0] = p0;
-          pk_s[ch] = fmaxf(pk_s[ch], fabsf(xf));
-          if constexpr (TP != 0) {
-            float m = 0.f;
-#pragma unroll
-            for (int ph = 0; ph < K::NPH; ++ph) {
-              float o = 0.f;
-#pragma unroll
-              for (int t2 = 0; t2 < K::NTAP; ++t2)
-                o = fmaf(F.tp[ph * K::NTAP + t2], w[ch][HX + u - t2], o);
-              m = fmaxf(m, fabsf(o));
-            }
-            if (tail) m = (j0 + u < nvalid) ? m : 0.f;
-            pk_t[ch] = fmaxf(pk_t[ch], m);
-          }
-        }
+        for (int u = 0; u < U; ++u) LGD_PEAKS(u);
+      }
     }
-    double e = 0.0;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) e = fma((double)F.w[ch], ech[ch], e);
+#undef LGD_PEAKS
+#undef LGD_X
 
     // ---- 100 ms sub-block sums: deterministic per-lane accumulate + wave tree
-    long long rel = (long long)k * LGD_WAVE + lane - cur_q;
-    for (;;) {
-      const bool mine = rel >= 0 && rel < F.lps;
-      acc += mine ? e : 0.0;
-      if ((long long)k * LGD_WAVE + LGD_WAVE >= cur_q + F.lps) {  // `cur` ends in this tile
-        const double tot = wave_sum_f64(acc);
-        if (lane == 0 && cur < sg.n_sb) ((double LGD_GLOBAL *)sg.e_out)[cur] = tot;
-        acc = 0.0;
-        ++cur;
-        cur_q += F.lps;
-        rel -= F.lps;
-      } else {
-        break;
+    if (filt) {
+      long long rel = (long long)k * LGD_WAVE + lane - cur_q;
+      for (;;) {
+        const bool mine = rel >= 0 && rel < lps;
+        acc += mine ? e : 0.0;
+        if ((long long)k * LGD_WAVE + LGD_WAVE >= cur_q + lps) {  // `cur` ends in this tile
+          const double tot = wave_sum_f64(acc) * pb0sq;
+          if (lane == 0 && cur < sg.n_sb)
+            ((double LGD_GLOBAL *)sg.e_out)[(long long)ch * sg.e_ch_stride + cur] = tot;
+          acc = 0.0;
+          ++cur;
+          cur_q += lps;
+          rel -= lps;
+        } else {
+          break;
+        }
       }
     }
   }
 
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    const float s = wave_max_f32(pk_s[ch]);
-    const float t = wave_max_f32(pk_t[ch]);
+  {
+    const float s = wave_max_f32(pk_s);
+    const float t = wave_max_f32(pk_t);
     if (lane == 0) {
       ((float LGD_GLOBAL *)sg.peak_out)[ch] = s;
-      ((float LGD_GLOBAL *)sg.peak_out)[NCH + ch] = t;
+      ((float LGD_GLOBAL *)sg.peak_out)[nch + ch] = t;
     }
   }
+#undef F
 }
 
 // ------------------------------------------------------- launch wrappers ---
-template <int C, int NCH, int TP>
-static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, const LgdFilt &F, hipStream_t s) {
-  hipLaunchKernelGGL((lgd_scan_kernel<C, NCH, TP>), dim3(n_seg), dim3(LGD_WAVE), 0, s, segs, F);
+template <int C, int G, int TP>
+static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, const LgdFilt *F, int nch,
+                                hipStream_t s) {
+  using K = ScanCfg<C, TP>;
+  const size_t lds_bytes = ((size_t)(K::TILE_F + K::HALO) * nch + 4) * sizeof(float);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)lgd_scan_kernel<C, G, TP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((lgd_scan_kernel<C, G, TP>), dim3(n_seg), dim3(LGD_WAVE * nch), lds_bytes, s,
+                     segs, F, nch);
   return hipGetLastError();
 }
 
-template <int C>
-static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, const LgdFilt &F,
+template <int C, int TP>
+static hipError_t launch_scan_g(int nch, const LgdSeg *segs, int n_seg, const LgdFilt *F,
                                 hipStream_t s) {
-  if (nch == 1) {
-    if (tp == 4) return launch_scan_t<C, 1, 4>(segs, n_seg, F, s);
-    if (tp == 2) return launch_scan_t<C, 1, 2>(segs, n_seg, F, s);
-    return launch_scan_t<C, 1, 0>(segs, n_seg, F, s);
-  }
-  if (tp == 4) return launch_scan_t<C, 2, 4>(segs, n_seg, F, s);
-  if (tp == 2) return launch_scan_t<C, 2, 2>(segs, n_seg, F, s);
-  return launch_scan_t<C, 2, 0>(segs, n_seg, F, s);
+  if (nch == 1) return launch_scan_t<C, 1, TP>(segs, n_seg, F, nch, s);
+  if (nch == 2) return launch_scan_t<C, 2, TP>(segs, n_seg, F, nch, s);
+  return launch_scan_t<C, 0, TP>(segs, n_seg, F, nch, s);
+}
+
+template <int C>
+static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, const LgdFilt *F,
+                                hipStream_t s) {
+  if (tp == 4) return launch_scan_g<C, 4>(nch, segs, n_seg, F, s);
+  if (tp == 2) return launch_scan_g<C, 2>(nch, segs, n_seg, F, s);
+  return launch_scan_g<C, 0>(nch, segs, n_seg, F, s);
 }
 
 // chunk lengths compiled in; the host picks one that divides the rate's s100
 extern "C" const int lgd_chunk_table[] = {25, 35, 45, 49, 50, 63, 75, 0};
 
+// LDS bytes one workgroup needs (host-side planning)
+extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp) {
+  const int halo = tp == 2 ? 24 : 12;
+  return ((size_t)(LGD_WAVE * chunk + halo) * nch + 4) * sizeof(float);
+}
+
+// F: DEVICE pointer to the group's constants
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
                                       const LgdFilt *F, hipStream_t s) {
   if (n_seg <= 0) return hipSuccess;
+  if (nch < 1 || nch > 16) return hipErrorInvalidValue;
   switch (chunk) {
-    case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, *F, s);
-    case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, *F, s);
-    case 45: return launch_scan_c<45>(nch, tp, segs, n_seg, *F, s);
-    case 49: return launch_scan_c<49>(nch, tp, segs, n_seg, *F, s);
-    case 50: return launch_scan_c<50>(nch, tp, segs, n_seg, *F, s);
-    case 63: return launch_scan_c<63>(nch, tp, segs, n_seg, *F, s);
-    case 75: return launch_scan_c<75>(nch, tp, segs, n_seg, *F, s);
+    case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, F, s);
+    case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, F, s);
+    case 45: return launch_scan_c<45>(nch, tp, segs, n_seg, F, s);
+    case 49: return launch_scan_c<49>(nch, tp, segs, n_seg, F, s);
+    case 50: return launch_scan_c<50>(nch, tp, segs, n_seg, F, s);
+    case 63: return launch_scan_c<63>(nch, tp, segs, n_seg, F, s);
+    case 75: return launch_scan_c<75>(nch, tp, segs, n_seg, F, s);
     default: return hipErrorInvalidValue;
   }
 }
-

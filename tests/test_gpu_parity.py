@@ -61,6 +61,23 @@ def test_ragged_lengths(scanner, oracle, frames):
     check_track(got, ref)
 
 
+@pytest.mark.parametrize("rate,nch", [(48000, 3), (48000, 4), (48000, 5), (48000, 6), (44100, 6),
+                                      (48000, 8), (96000, 6), (48000, 16)])
+def test_multichannel(scanner, oracle, rate, nch):
+    """libebur128 default channel map by index: 4ch L R Ls Rs; 5ch L R C Ls Rs;
+    otherwise L R C UNUSED Ls Rs UNUSED...; surrounds weigh 1.41; peaks include
+    the unused channels."""
+    frames = int(rate * 9.3) + 17
+    pcm = synth.track_numpy(frames, nch, rate, seed=100 + nch, step_s=1.7)
+    # different level per channel so that a wrong weight or mapping shows
+    gains = np.array([1.0, 0.7, 0.5, 1.3, 0.9, 0.6, 1.1, 0.8] * 2)[:nch].astype(np.float32)
+    pcm = synth.snap_s16_numpy(pcm * gains[None, :])
+    ref = oracle.scan_track(pcm, rate)
+    (got,), _ = scanner.scan([to_dev(pcm)], rate)
+    check_track(got, ref, rate=rate)
+    assert got["sample_peak"] == max(ref["sample_peak"])
+
+
 def test_silence_and_full_scale(scanner, oracle):
     sil = np.zeros((48000 * 5, 2), np.float32)
     (got,), _ = scanner.scan([to_dev(sil)], 48000)
@@ -154,6 +171,8 @@ def test_errors(scanner):
         scanner.plan([(x.data_ptr(), 4800, 0)], 48000)   # 0 channels
     with pytest.raises(LoudscanError):
         scanner.plan([(x.data_ptr(), 4800, 65)], 48000)  # > 64 channels
+    with pytest.raises(LoudscanError):
+        scanner.plan([(x.data_ptr(), 100, 17)], 48000)   # 17..64: not covered yet
     with pytest.raises(LoudscanError):
         scanner.plan([(x.data_ptr() + 4, 100, 2)], 48000)  # misaligned
     with pytest.raises(LoudscanError):

@@ -3,10 +3,10 @@ set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu.log
 rm -f gpurun_out/bench_sweep.log
-for c in 25 50 75; do for w in 3 4 6 8; do
+for c in 25 50 75; do for w in 4 8 12 16; do
   timeout -k 10 300 python bench.py --steps 30 --warmup 3 --chunk $c --waves-per-cu $w --no-cpu-baseline >> gpurun_out/bench_sweep.log 2>&1 || echo "bench fail c=$c w=$w"
 done; done
-for c in 25 50; do for w in 4 8; do
+for c in 25 50 75; do for w in 8 16; do
 timeout -k 10 300 python bench.py --steps 30 --warmup 3 --workload c3 --chunk $c --waves-per-cu $w --no-cpu-baseline >> gpurun_out/bench_sweep.log 2>&1
 done; done
 python - <<'PY'
