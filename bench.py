@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--warm-subblocks", type=int, default=-1)
     ap.add_argument("--cpu-seconds", type=int, default=1800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug", type=int, default=0, help="kernel floor measurement: 1 no loads, 2 no arithmetic")
     args = ap.parse_args()
 
     import torch
@@ -92,6 +93,8 @@ def main():
         sc.set_param("waves_per_cu", args.waves_per_cu)
     if args.warm_subblocks >= 0:
         sc.set_param("warm_subblocks", args.warm_subblocks)
+    if args.debug:
+        sc.set_param("debug", args.debug)
     stream = torch.cuda.Stream(device=dev)
     if world > 1:
         job = DistributedAlbumScanner(sc, [pcm], rate, true_peak=true_peak)

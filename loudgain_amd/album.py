@@ -74,6 +74,21 @@ class DeviceShard:
         return self.sc.fetch()
 
 
+def _on_wire(t, group):
+    """RCCL moves HBM tensors directly.  Any other backend (gloo in the tests)
+    gets a host copy of the few bytes being exchanged."""
+    import torch.distributed as dist
+    return t if (not t.is_cuda or dist.get_backend(group) == "nccl") else t.cpu()
+
+
+def _all_reduce(t, op, group):
+    import torch.distributed as dist
+    w = _on_wire(t, group)
+    dist.all_reduce(w, op=op, group=group)
+    if w is not t:
+        t.copy_(w)
+
+
 def reduce_album(shard, group=None, st_slots_max=None):
     """Run the three-step protocol over `shard` (DeviceShard, or any object with
     part1 / part2 tensors and stage2() / st_energies() / finish()).  Collectives
@@ -84,22 +99,28 @@ def reduce_album(shard, group=None, st_slots_max=None):
     p1, p2 = shard.part1, shard.part2
     if world > 1:
         peak = p1[2:3].clone()
-        dist.all_reduce(p1, op=dist.ReduceOp.SUM, group=group)       # sum_abs, n_abs, (peak), n_st
-        dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=group)
+        _all_reduce(p1, dist.ReduceOp.SUM, group)       # sum_abs, n_abs, (peak), n_st
+        _all_reduce(peak, dist.ReduceOp.MAX, group)
         p1[2:3].copy_(peak)
     shard.stage2()
     if world > 1:
-        dist.all_reduce(p2, op=dist.ReduceOp.SUM, group=group)       # sum_rel, n_rel
+        _all_reduce(p2, dist.ReduceOp.SUM, group)       # sum_rel, n_rel
     st = shard.st_energies()
     if world > 1:
         if st_slots_max is None:
             m = torch.tensor([st.numel()], dtype=torch.int64, device=st.device)
-            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+            _all_reduce(m, dist.ReduceOp.MAX, group)
             st_slots_max = int(m.item())
         pad = torch.zeros(st_slots_max, dtype=torch.float64, device=st.device)  # 0.0 == unlisted
         pad[:st.numel()].copy_(st)
         st_all = torch.empty(st_slots_max * world, dtype=torch.float64, device=st.device)
-        dist.all_gather_into_tensor(st_all, pad, group=group)
+        wire_in = _on_wire(pad, group)
+        if wire_in is pad:
+            dist.all_gather_into_tensor(st_all, pad, group=group)
+        else:
+            parts = [torch.empty_like(wire_in) for _ in range(world)]
+            dist.all_gather(parts, wire_in, group=group)
+            st_all.copy_(torch.cat(parts))
     else:
         st_all = st
     shard.finish(st_all)
@@ -119,7 +140,7 @@ class DistributedAlbumScanner:
         n = self.shard.st.numel()
         if self.world > 1:
             m = torch.tensor([n], dtype=torch.int64, device=self.shard.device)
-            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+            _all_reduce(m, dist.ReduceOp.MAX, group)
             n = int(m.item())
         self.st_slots_max = n
 

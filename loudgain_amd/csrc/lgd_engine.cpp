@@ -172,7 +172,7 @@ static const size_t MAX_GROUPS = 64;  // distinct (rate, channels) pairs per pla
 
 struct lgd_ctx {
   int device = 0;
-  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 3, p_waves_per_cu = 8;
+  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 3, p_waves_per_cu = 8, p_debug = 0;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -277,6 +277,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "seg_subblocks")) c->p_seg_sb = value;
   else if (!strcmp(name, "warm_subblocks")) c->p_warm_sb = value;
   else if (!strcmp(name, "waves_per_cu")) c->p_waves_per_cu = value ? value : 8;
+  else if (!strcmp(name, "debug")) c->p_debug = value;  // kernel floor measurements only
   else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
   c->planned = false;
   return LGD_OK;
@@ -382,6 +383,7 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     g.F.pbn[1] = g.F.pb[2] / g.F.pb[0];
     g.F.pb0sq = g.F.pb[0] * g.F.pb[0];
     g.F.lps = s100 / g.chunk;
+    g.F.pad = (int)c->p_debug;
     g.seg_begin = c->segs.size();
     const long long tile_f = 64LL * g.chunk;
     const int warm_tiles =

@@ -428,3 +428,29 @@ extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *
   hipLaunchKernelGGL(lgd_album_final_kernel, dim3(1), dim3(1), 0, s, part1, part2, rel_factor, album);
   return hipGetLastError();
 }
+
+// ---- PCM ingest: interleaved S16 -> f32 on the S16 grid (x / 32768, exact).
+// The reference converts every decoded frame to S16 (scan.c:414,442) and
+// libebur128 scales by 1/32768; uploading S16 halves the PCIe bytes.
+__global__ __launch_bounds__(256) void lgd_s16_to_f32_kernel(const short *__restrict__ in,
+                                                             float *__restrict__ out,
+                                                             size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 8 <= n && (((uintptr_t)(in + i)) & 15) == 0 && (((uintptr_t)(out + i)) & 15) == 0) {
+    const short4 a = *reinterpret_cast<const short4 *>(in + i);
+    const short4 b = *reinterpret_cast<const short4 *>(in + i + 4);
+    const float k = 1.0f / 32768.0f;
+    *reinterpret_cast<float4 *>(out + i) = make_float4(a.x * k, a.y * k, a.z * k, a.w * k);
+    *reinterpret_cast<float4 *>(out + i + 4) = make_float4(b.x * k, b.y * k, b.z * k, b.w * k);
+  } else {
+    for (size_t j = i; j < n && j < i + 8; ++j) out[j] = (float)in[j] * (1.0f / 32768.0f);
+  }
+}
+
+extern "C" hipError_t lgd_launch_s16_to_f32(const short *in, float *out, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  const size_t nthreads = (n + 7) / 8;
+  hipLaunchKernelGGL(lgd_s16_to_f32_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s,
+                     in, out, n);
+  return hipGetLastError();
+}

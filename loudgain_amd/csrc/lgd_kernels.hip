@@ -47,10 +47,23 @@ typedef const f32x4 LGD_GLOBAL *gvec_ptr;
 typedef const float LGD_GLOBAL *gflt_ptr;
 
 // ---------------------------------------------------------------- helpers ---
+// Wave-wide sums through the DPP cross-lane paths of the VALU (no LDS round trip
+// as with ds_bpermute): butterfly inside each row of 16 lanes, then the row
+// totals travel by row_bcast.  Fixed order -> reproducible.  Total in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, LGD_WAVE);
-  return v;
+  v += dpp_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_f64<0x140, 0xF>(v);  // row_mirror: every lane holds its row's sum
+  v += dpp_f64<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_f64<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return __shfl(v, LGD_WAVE - 1, LGD_WAVE);
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
@@ -67,6 +80,21 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // G   channels == waves per workgroup; 0 = run-time value (frame stride in LDS
 //     is then a register instead of an immediate)
 // TP  0 = no interpolator (>= 192 kHz or disabled), 4 = 4x, 2 = 2x
+// LDS layout of a staged tile.
+//  G == 0 (run-time channel count): interleaved as in memory, frame stride nch.
+//  G == 1, 2: PLANAR, one plane per channel, and every lane's C-frame chunk is
+//  followed by PAD unused floats so that the lane stride C + PAD is odd: 64 lanes
+//  reading the same chunk position then hit 32 different banks (an even stride,
+//  e.g. interleaved stereo, costs 2..32-way ds_read conflicts).
+//  Frame f (tile-relative, f >= -HALO) of a plane sits at
+//     PO + f + floor(f / C) * PAD,   PO = HALO + PAD + (run-time alignment shift)
+template <int C, int G>
+struct LdsLayout {
+  static constexpr bool PLANAR = (G == 1 || G == 2);
+  static constexpr int PAD = (PLANAR && (C % 2 == 0)) ? 1 : 0;
+  static constexpr int STRIDE = C + PAD;  // lane stride inside a plane
+};
+
 template <int C, int TP>
 struct ScanCfg {
   static constexpr int HALO = (TP == 2) ? 24 : 12;     // frames kept before the tile
@@ -84,8 +112,11 @@ struct ScanCfg {
 // (launch bounds: G waves per workgroup, >= 2 waves per SIMD wanted -> <= 256 VGPRs;
 // the run-time-G variant must fit 16 waves -> <= 128 VGPRs, so the host gives it
 // short chunks)
+// The interpolator variants are pinned to exactly 2 waves per SIMD: left alone,
+// hipcc aims for 3 and spills the FIR window to scratch.
 template <int C, int G, int TP>
-__global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_kernel(
+__global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ? LGD_WAVE * G : 1024),
+                          amdgpu_waves_per_eu(G ? 2 : 4, (G && TP) ? 2 : 4))) void lgd_scan_kernel(
     const LgdSeg *__restrict__ segs, const LgdFilt *__restrict__ Fg, const int nch_rt) {
   using K = ScanCfg<C, TP>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -106,6 +137,12 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
   const int shift = (int)((sg.f0 * nch) & 3);
   const long long n_frames = sg.n_floats / nch;
   const int nvec = ((K::TILE_F + K::HALO) * nch + 4) >> 2;  // 16-B vectors per tile
+  using LL = LdsLayout<C, G>;
+  // vector i of a thread is in range for EVERY thread when this holds (compile-time
+  // for the fixed-channel-count kernels: no exec masking around full vectors)
+#define LGD_VEC_ALWAYS(i_) (G != 0 && (LGD_WAVE * G) * ((i_) + 1) <= (((K::TILE_F + K::HALO) * G + 4) >> 2))
+  // floats per plane: HALO + shift slack + 64 padded chunks (+ tail slack), even
+  constexpr int PLANE = (K::HALO + 4 + LL::PAD + LGD_WAVE * LL::STRIDE + 4 + 1) & ~1;
   const bool filt = lgd_channel_weight(ch, nch) > 0.0;       // wave-uniform
 
   const double ra1 = F.ra[0], ra2 = F.ra[1], pa1 = F.pa[0], pa2 = F.pa[1];
@@ -113,6 +150,7 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
   const double alpha = F.alpha, beta = F.beta, gamma_ = F.gamma, inv_alpha = F.inv_alpha,
                inv_beta = F.inv_beta, dcg = F.dc, pb0sq = F.pb0sq;
   const int lps = F.lps;
+  const int dbg = F.pad;  // measurement only: 1 = no global loads, 2 = no arithmetic
   float tpc[K::NPH * K::NTAP + 1];
 #pragma unroll
   for (int i = 0; i < K::NPH * K::NTAP; ++i) tpc[i] = F.tp[i];
@@ -120,7 +158,7 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
   double cin[4] = {0.0, 0.0, 0.0, 0.0};  // wave-uniform filter state entering the tile
   double acc = 0.0;       // this lane's share of sub-block `cur`
   int cur = 0;            // sub-block (relative to the segment) being summed
-  long long cur_q = 0;    // chunk index (relative to f0) where `cur` starts
+  int cur_q = 0;          // chunk index (relative to f0) where `cur` starts
   float pk_s = 0.f, pk_t = 0.f;
 
   const int n_main = (int)((sg.f_peak_end - sg.f0 + K::TILE_F - 1) / K::TILE_F);
@@ -138,11 +176,12 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
   do {                                                                                  \
     const long long g0_ = LGD_TILE_G0(kk); /* float index of lds[0], multiple of 4 */   \
     pf_valid = (g0_ >= 0) && (g0_ + 4LL * nvec <= sg.n_floats); /* block-uniform */     \
+    if (dbg & 1) pf_valid = false;                                                      \
     if (pf_valid) {                                                                     \
       const gvec_ptr src_ = (gvec_ptr)(sg.pcm + g0_);                                   \
       _Pragma("unroll") for (int i_ = 0; i_ < K::NV; ++i_) {                            \
         const int idx_ = tid + nthreads * i_;                                           \
-        if (idx_ < nvec) pf[i_] = src_[idx_];                                           \
+        if ((LGD_VEC_ALWAYS(i_) || idx_ < nvec) && !(dbg & 32)) pf[i_] = src_[idx_];    \
       }                                                                                 \
     }                                                                                   \
   } while (0)
@@ -151,13 +190,35 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
   for (int k = -sg.n_warm_tiles; k < n_main; ++k) {
     const long long tb = sg.f0 + (long long)k * K::TILE_F;  // first frame of the tile
     __syncthreads();  // every wave is done reading the previous tile
-    if (pf_valid) {
+    // LDS slot of frame f of a plane (planar layouts): PO_W + f + floor(f / C) * PAD,
+    // written in terms of the vector's own frame slot jj = f + HALO + shift / G
+#define LGD_STORE_VEC(idx_, v_)                                                          \
+    do {                                                                                 \
+      if constexpr (!LL::PLANAR) {                                                       \
+        *reinterpret_cast<f32x4 *>(lds + 4 * (idx_)) = (v_);                             \
+      } else if constexpr (G == 1 && LL::PAD == 0) {                                     \
+        *reinterpret_cast<f32x4 *>(lds + 4 * (idx_)) = (v_);                             \
+      } else if constexpr (G == 2 && LL::PAD == 0) {                                     \
+        const int jj_ = 2 * (idx_);                                                      \
+        *reinterpret_cast<float2 *>(lds + jj_) = make_float2((v_).x, (v_).z);            \
+        *reinterpret_cast<float2 *>(lds + PLANE + jj_) = make_float2((v_).y, (v_).w);    \
+      } else {                                                                           \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                               \
+          const int i_ = 4 * (idx_) + e_;                                                \
+          const int c_ = i_ % G, jj_ = i_ / G;                                           \
+          /* f + C >= 0 always (HALO <= C): floor(f / C) = (f + C) / C - 1 */            \
+          const int fpc_ = jj_ - K::HALO - shift / G + C;                                \
+          lds[c_ * PLANE + jj_ + LL::PAD * (int)((unsigned)fpc_ / (unsigned)C)] = (v_)[e_]; \
+        }                                                                                \
+      }                                                                                  \
+    } while (0)
+    if (pf_valid && !(dbg & 64)) {
 #pragma unroll
       for (int i = 0; i < K::NV; ++i) {
         const int idx = tid + nthreads * i;
-        if (idx < nvec) *reinterpret_cast<f32x4 *>(lds + 4 * idx) = pf[i];
+        if (LGD_VEC_ALWAYS(i) || idx < nvec) LGD_STORE_VEC(idx, pf[i]);
       }
-    } else {
+    } else if (!(dbg & 1) && !(dbg & 64)) {
       const long long g0 = LGD_TILE_G0(k);
       const gflt_ptr gp = (gflt_ptr)sg.pcm;
       for (int i = tid; i < nvec; i += nthreads) {
@@ -171,9 +232,10 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
           v.z = (g + 2 >= 0 && g + 2 < sg.n_floats) ? gp[g + 2] : 0.f;
           v.w = (g + 3 >= 0 && g + 3 < sg.n_floats) ? gp[g + 3] : 0.f;
         }
-        *reinterpret_cast<f32x4 *>(lds + 4 * i) = v;
+        LGD_STORE_VEC(i, v);
       }
     }
+#undef LGD_STORE_VEC
     __syncthreads();
     if (k + 1 < n_main) LGD_PREFETCH(k + 1); else pf_valid = false;
 
@@ -181,13 +243,17 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
     // stride nch floats, streamed from LDS U frames at a time
     constexpr int U = K::U;
     constexpr int HX = K::HX;
-    const float *chunk = lds + shift + (K::HALO + lane * C) * nch + ch;
-#define LGD_X(j) chunk[(j) * (G ? G : nch)]
+    // this lane's chunk; LGD_X(j) = frame j of it (j < 0: history in the previous chunk)
+    const float *chunk = LL::PLANAR
+        ? lds + ch * PLANE + (K::HALO + shift / (G ? G : 1)) + lane * LL::STRIDE  // + PAD folded below
+        : lds + shift + (K::HALO + lane * C) * nch + ch;
+#define LGD_X(j) (LL::PLANAR ? chunk[(j) + ((j) < 0 ? 0 : LL::PAD)] : chunk[(j) * (G ? G : nch)])
 
     // per-tile opaque copy of the constants pointer: keeps the scan-matrix loads
     // inside the tile loop (scalar cache hits) instead of hoisted into SGPRs
     cfilt_ptr Fk = F0;
     asm volatile("" : "+s"(Fk));
+    if (dbg & 2) continue;
     double qs[2] = {0.0, 0.0}, ps[2] = {0.0, 0.0};
     if (filt) {
       // ---- A: zero-state run of q' = x/ra, p' = q'/pa over the chunk (4 FMAs per
@@ -197,11 +263,21 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
       double z[4];
       {
         double qv[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int j0 = 0; j0 < C; j0 += U) {
-          float xa[U];
+        // LDS reads run one step ahead of the arithmetic (software pipeline)
+        float xa[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) xa[u] = LGD_X(j0 + u);
+        for (int u = 0; u < U; ++u) xa[u] = LGD_X(u);
+        // drain here, so that inside the loop the only LDS reads in flight are the
+        // NEXT step's (hipcc otherwise merges the pre-loop state into the loop and
+        // waits for the reads it has just issued)
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#pragma unroll 1
+        for (int j0 = (dbg & 4) ? C : 0; j0 < C; j0 += U) {
+          float xn[U];
+          if (j0 + U < C) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
+          }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             double t = fma(-ra2, qv[1], (double)xa[u]);
@@ -211,6 +287,8 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
             qv[3] = qv[2]; qv[2] = qv[1]; qv[1] = qv[0]; qv[0] = q0;
             pv[3] = pv[2]; pv[2] = pv[1]; pv[1] = pv[0]; pv[0] = p0;
           }
+#pragma unroll
+          for (int u = 0; u < U; ++u) xa[u] = xn[u];
         }
         const double q1 = (qv[0] - 2.0 * qv[1]) + qv[2];
         const double q2 = (qv[1] - 2.0 * qv[2]) + qv[3];
@@ -239,6 +317,7 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
       }
 #pragma unroll
       for (int s = 0; s < 6; ++s) {
+        if (dbg & 8) break;
         const int d = 1 << s;
         const auto *P = Fk->P[s];
         double u[4];
@@ -297,11 +376,28 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
     } while (0)
     if (filt) {
       double xh0 = (double)LGD_X(-1), xh1 = (double)LGD_X(-2);
-#pragma unroll 1
-      for (int j0 = 0; j0 < C; j0 += U) {
-        float w[U + HX];  // frames j0-HX .. j0+U-1
+      float w[U + HX];  // frames j0-HX .. j0+U-1
+      // without the interpolator the next U frames are fetched a step ahead of
+      // the arithmetic; with it the window is re-read per step (shifting an
+      // 11..23-frame window through registers costs more than the LDS reads)
+      constexpr bool PIPE = (TP == 0);
+      if constexpr (PIPE) {
 #pragma unroll
-        for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
+        for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(i - HX);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see phase A
+      }
+#pragma unroll 1
+      for (int j0 = (dbg & 16) ? C : 0; j0 < C; j0 += U) {
+        float xn[U];
+        if constexpr (PIPE) {
+          if (j0 + U < C) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const double x = (double)w[HX + u];
@@ -318,6 +414,10 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
           qs[1] = qs[0]; qs[0] = q0;
           ps[1] = ps[0]; ps[0] = p0;
           LGD_PEAKS(u);
+        }
+        if constexpr (PIPE) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) w[HX + u] = xn[u];
         }
       }
     } else {
@@ -336,11 +436,11 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
 
     // ---- 100 ms sub-block sums: deterministic per-lane accumulate + wave tree
     if (filt) {
-      long long rel = (long long)k * LGD_WAVE + lane - cur_q;
+      int rel = k * LGD_WAVE + lane - cur_q;  // (the host keeps tiles per segment < 2^24)
       for (;;) {
         const bool mine = rel >= 0 && rel < lps;
         acc += mine ? e : 0.0;
-        if ((long long)k * LGD_WAVE + LGD_WAVE >= cur_q + lps) {  // `cur` ends in this tile
+        if (k * LGD_WAVE + LGD_WAVE >= cur_q + lps) {  // `cur` ends in this tile
           const double tot = wave_sum_f64(acc) * pb0sq;
           if (lane == 0 && cur < sg.n_sb)
             ((double LGD_GLOBAL *)sg.e_out)[(long long)ch * sg.e_ch_stride + cur] = tot;
@@ -367,11 +467,22 @@ __global__ __launch_bounds__(G ? LGD_WAVE * G : 1024, G ? 2 : 4) void lgd_scan_k
 }
 
 // ------------------------------------------------------- launch wrappers ---
+// LDS bytes one workgroup needs (also used by the host-side planner); mirrors
+// LdsLayout / PLANE in the kernel
+extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp) {
+  const int halo = tp == 2 ? 24 : 12;
+  if (nch <= 2) {
+    const int pad = (chunk % 2 == 0) ? 1 : 0;
+    const int plane = (halo + 4 + pad + LGD_WAVE * (chunk + pad) + 4 + 1) & ~1;
+    return (size_t)nch * plane * sizeof(float);
+  }
+  return ((size_t)(LGD_WAVE * chunk + halo) * nch + 4) * sizeof(float);
+}
+
 template <int C, int G, int TP>
 static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, const LgdFilt *F, int nch,
                                 hipStream_t s) {
-  using K = ScanCfg<C, TP>;
-  const size_t lds_bytes = ((size_t)(K::TILE_F + K::HALO) * nch + 4) * sizeof(float);
+  const size_t lds_bytes = lgd_scan_lds_bytes(C, nch, TP);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)lgd_scan_kernel<C, G, TP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -399,13 +510,8 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
 }
 
 // chunk lengths compiled in; the host picks one that divides the rate's s100
-extern "C" const int lgd_chunk_table[] = {25, 35, 45, 49, 50, 63, 75, 0};
+extern "C" const int lgd_chunk_table[] = {25, 35, 40, 42, 45, 48, 49, 50, 60, 63, 70, 75, 0};
 
-// LDS bytes one workgroup needs (host-side planning)
-extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp) {
-  const int halo = tp == 2 ? 24 : 12;
-  return ((size_t)(LGD_WAVE * chunk + halo) * nch + 4) * sizeof(float);
-}
 
 // F: DEVICE pointer to the group's constants
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
@@ -415,6 +521,11 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, const LgdSeg *
   switch (chunk) {
     case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, F, s);
     case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, F, s);
+    case 40: return launch_scan_c<40>(nch, tp, segs, n_seg, F, s);
+    case 42: return launch_scan_c<42>(nch, tp, segs, n_seg, F, s);
+    case 48: return launch_scan_c<48>(nch, tp, segs, n_seg, F, s);
+    case 60: return launch_scan_c<60>(nch, tp, segs, n_seg, F, s);
+    case 70: return launch_scan_c<70>(nch, tp, segs, n_seg, F, s);
     case 45: return launch_scan_c<45>(nch, tp, segs, n_seg, F, s);
     case 49: return launch_scan_c<49>(nch, tp, segs, n_seg, F, s);
     case 50: return launch_scan_c<50>(nch, tp, segs, n_seg, F, s);

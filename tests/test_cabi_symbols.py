@@ -1,0 +1,56 @@
+"""CPU: the C-ABI shared library loads and exports every symbol that
+include/loudscan.h and include/loudscan_device.h declare (no compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:scan|lgd)_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from loudgain_amd import _lib, scan
+    L = _lib.load()
+    dev = _declared("loudscan_device.h")
+    api = _declared("loudscan.h")
+    assert len(dev) >= 15 and len(api) >= 14
+    for name in dev + api:
+        assert hasattr(L, name), "missing export: " + name
+    assert sorted(_lib.DEVICE_SYMBOLS) == dev
+    assert sorted(scan.SCAN_SYMBOLS) == api
+
+
+def test_scan_result_layout_matches_reference_header():
+    # /root/reference/src/scan.h:35-53 on LP64: 2 pointers, int (+pad), 9 doubles = 96 bytes
+    from loudgain_amd.scan import ScanResult
+    assert ctypes.sizeof(ScanResult) == 96
+    names = [f[0] for f in ScanResult._fields_]
+    assert names == ["file", "container", "codec_id", "track_gain", "track_peak", "track_loudness",
+                     "track_loudness_range", "album_gain", "album_peak", "album_loudness",
+                     "album_loudness_range", "loudness_reference"]
+    assert ScanResult.track_gain.offset == 24 and ScanResult.loudness_reference.offset == 88
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the product refuses to run instead of computing on the CPU."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from loudgain_amd.device import DeviceScanner, LoudscanError
+    with pytest.raises(LoudscanError):
+        DeviceScanner(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "loudgain_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "lgoracle" not in txt and "liblgoracle" not in txt and "lg_oracle" not in txt, f
