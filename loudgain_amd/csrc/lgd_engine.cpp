@@ -141,23 +141,32 @@ static int interp_factor(unsigned rate) { return rate < 96000 ? 4 : (rate < 1920
 
 // 49-tap Hann-windowed sinc split into polyphase branches.
 // Branch 0 is a pure delay (its maximum is the sample peak), so only the
-// non-trivial branches are kept: 3 x 12 taps (4x) or 1 x 24 taps (2x); tap t of
-// a branch multiplies x[n - t].
+// non-trivial branches matter: 3 x 12 taps (4x) or 1 x 24 taps (2x); tap t of a
+// branch multiplies x[n - t].  The prototype is symmetric about tap 24, so 4x
+// branch 3 is branch 1 reversed and branch 2 (like the 2x branch) is its own
+// mirror; the kernel gets the unique values only:
+//   tp[0..11]  = 4x branch 1 (branch 3 = reversed) | 2x branch, first half
+//   tp[12..17] = 4x branch 2, first half
+// (a mirrored pair can differ by one double ulp in libebur128's own table,
+// i.e. < 1e-16 of an output that is compared at 1e-4).
 static void design_interp(int factor, float tp[36]) {
   const double pi = 3.14159265358979323846264338327950288;
   memset(tp, 0, 36 * sizeof(float));
   if (!factor) return;
+  double br[4][25];
   int count[4] = {0, 0, 0, 0};
-  const int ntap = factor == 4 ? 12 : 24;
   for (int j = 0; j < 49; ++j) {
     const double m = (double)j - 24.0;
     double c = 1.0;
     if (std::fabs(m) > 0.000001) c = std::sin(m * pi / factor) / (m * pi / factor);
     c *= 0.5 * (1.0 - std::cos(2.0 * pi * j / 48.0));
-    if (std::fabs(c) > 0.000001) {
-      const int f = j % factor, t = count[f]++;
-      if (f > 0 && t < ntap) tp[(f - 1) * ntap + t] = (float)c;  // index j / factor == t
-    }
+    if (std::fabs(c) > 0.000001) br[j % factor][count[j % factor]++] = c;  // index j / factor == slot
+  }
+  if (factor == 4) {
+    for (int t = 0; t < 12; ++t) tp[t] = (float)br[1][t];
+    for (int t = 0; t < 6; ++t) tp[12 + t] = (float)br[2][t];
+  } else {
+    for (int t = 0; t < 12; ++t) tp[t] = (float)br[1][t];
   }
 }
 
@@ -172,7 +181,7 @@ static const size_t MAX_GROUPS = 64;  // distinct (rate, channels) pairs per pla
 
 struct lgd_ctx {
   int device = 0;
-  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 3, p_waves_per_cu = 8, p_debug = 0;
+  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -185,19 +194,29 @@ struct lgd_ctx {
   std::vector<Group> groups;
   uint64_t total_sb = 0, total_e = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0,
            warm_bytes = 0;
-  // device workspace
-  double *d_E = nullptr, *d_Z = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
-  double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr;  // per-slice gating partials
+  // device workspace.  Everything a scan writes exists twice (WorkSet): while
+  // the gating / LRA epilogue of scan k runs on the side stream, the dominant
+  // kernel of scan k+1 already runs on the caller's stream into the other set.
+  struct WorkSet {
+    double *d_E = nullptr, *d_Z = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
+    double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr;  // per-slice gating partials
+    double *d_part1 = nullptr, *d_part2 = nullptr;
+    float *d_peaks = nullptr;
+    LgdSeg *d_segs = nullptr;       // descriptors carry pointers into this set's E / peaks
+    LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
+    LgdRange *h_album_range = nullptr;  // pinned
+    size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_segs = 0,
+           cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0;
+    hipEvent_t ev_scan = nullptr, ev_done = nullptr;
+    bool busy = false;  // an epilogue of this set has been enqueued on the side stream
+  } ws[2];
+  int n_sets = 1;     // 2 unless the caller drives the album stages itself
+  int cur_set = 0;    // set of the last lgd_execute
+  hipStream_t side = nullptr;
   LgdSlice *d_slices = nullptr;
   LgdFilt *d_filt = nullptr;  // [MAX_GROUPS] per-group kernel constants
-  double *d_part1 = nullptr, *d_part2 = nullptr;
-  float *d_peaks = nullptr;
   LgdTrackMeta *d_meta = nullptr;
-  LgdSeg *d_segs = nullptr;
-  LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
-  LgdRange *h_album_range = nullptr;  // pinned
-  size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_meta = 0, cap_segs = 0,
-         cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0, cap_slices = 0;
+  size_t cap_meta = 0, cap_slices = 0;
   hipStream_t last_stream = nullptr;
   // ring of (start, scan kernel done, all done) event triples, one per execute
   static const int EV_RING = 64;
@@ -241,12 +260,17 @@ extern "C" lgd_ctx *lgd_create(int device) {
   memset(c->ev, 0, sizeof(c->ev));
   for (int i = 0; i < lgd_ctx::EV_RING; ++i)
     for (int j = 0; j < 3; ++j) ok = ok && hipEventCreate(&c->ev[i][j]) == hipSuccess;
-  ok = ok && hipMalloc((void **)&c->d_album, 16 * sizeof(double)) == hipSuccess;
-  ok = ok && hipMalloc((void **)&c->d_part1, 4 * sizeof(double)) == hipSuccess;
-  ok = ok && hipMalloc((void **)&c->d_part2, 2 * sizeof(double)) == hipSuccess;
-  ok = ok && hipMalloc((void **)&c->d_album_range, sizeof(LgdRange)) == hipSuccess;
+  for (auto &w : c->ws) {
+    ok = ok && hipMalloc((void **)&w.d_album, 16 * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&w.d_part1, 4 * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&w.d_part2, 2 * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&w.d_album_range, sizeof(LgdRange)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&w.h_album_range, sizeof(LgdRange)) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&w.ev_scan, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming) == hipSuccess;
+  }
+  ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->d_filt, MAX_GROUPS * sizeof(LgdFilt)) == hipSuccess;
-  ok = ok && hipHostMalloc((void **)&c->h_album_range, sizeof(LgdRange)) == hipSuccess;
   if (!ok) {
     fail(LGD_ENOMEM, "lgd_create: allocation failed");
     lgd_destroy(c);
@@ -258,12 +282,20 @@ extern "C" lgd_ctx *lgd_create(int device) {
 extern "C" void lgd_destroy(lgd_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  void *ptrs[] = {c->d_E, c->d_Z, c->d_st, c->d_res, c->d_album, c->d_part1, c->d_part2, c->d_peaks,
-                  c->d_meta, c->d_segs, c->d_ranges, c->d_album_range, c->d_p1, c->d_p2, c->d_p2a,
-                  c->d_slices, c->d_filt};
-  for (void *p : ptrs)
+  (void)hipDeviceSynchronize();
+  for (auto &w : c->ws) {
+    void *ptrs[] = {w.d_E, w.d_Z, w.d_st, w.d_res, w.d_album, w.d_part1, w.d_part2, w.d_peaks,
+                    w.d_segs, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a};
+    for (void *p : ptrs)
+      if (p) (void)hipFree(p);
+    if (w.h_album_range) (void)hipHostFree(w.h_album_range);
+    if (w.ev_scan) (void)hipEventDestroy(w.ev_scan);
+    if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+  }
+  void *ptrs2[] = {c->d_meta, c->d_slices, c->d_filt};
+  for (void *p : ptrs2)
     if (p) (void)hipFree(p);
-  if (c->h_album_range) (void)hipHostFree(c->h_album_range);
+  if (c->side) (void)hipStreamDestroy(c->side);
   for (int i = 0; i < lgd_ctx::EV_RING; ++i)
     for (int j = 0; j < 3; ++j)
       if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
@@ -420,37 +452,46 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     c->groups.push_back(g);
   }
 
+  // the caller-driven (multi-GPU) album keeps one set: its partial pointers are
+  // handed out once and the stages run on the caller's stream
+  HIPCHK(hipDeviceSynchronize());  // nothing of an older plan may still be running
+  c->n_sets = (flags & LGD_FLAG_ALBUM_PART1) ? 1 : 2;
+  c->cur_set = 0;
   int rc;
-  if ((rc = ensure(&c->d_E, &c->cap_E, c->total_e))) return rc;
-  if ((rc = ensure(&c->d_Z, &c->cap_Z, c->total_sb))) return rc;
-  if ((rc = ensure(&c->d_p1, &c->cap_p1, 4 * c->slices.size()))) return rc;
-  if ((rc = ensure(&c->d_p2, &c->cap_p2, 2 * c->slices.size()))) return rc;
-  if ((rc = ensure(&c->d_p2a, &c->cap_p2a, 2 * c->slices.size()))) return rc;
   if ((rc = ensure(&c->d_slices, &c->cap_slices, c->slices.size()))) return rc;
-  if ((rc = ensure(&c->d_st, &c->cap_st, c->total_st))) return rc;
-  if ((rc = ensure(&c->d_res, &c->cap_res, (size_t)n * LGR_STRIDE))) return rc;
-  if ((rc = ensure(&c->d_peaks, &c->cap_peaks, c->total_peak_floats))) return rc;
   if ((rc = ensure(&c->d_meta, &c->cap_meta, n))) return rc;
-  if ((rc = ensure(&c->d_segs, &c->cap_segs, c->segs.size()))) return rc;
-  if ((rc = ensure(&c->d_ranges, &c->cap_ranges, n))) return rc;
-
-  for (LgdSeg &sg : c->segs) {
-    sg.e_out = c->d_E + (uintptr_t)sg.e_out;
-    sg.peak_out = c->d_peaks + (uintptr_t)sg.peak_out;
-  }
   c->ranges.resize(n);
-  for (uint32_t t = 0; t < n; ++t) {
-    c->ranges[t].off = c->meta[t].st_off;
-    c->ranges[t].n = c->meta[t].n_st_slots;
-    c->ranges[t].out = c->d_res + (size_t)t * LGR_STRIDE + LGR_LRA;
+  for (int k = 0; k < c->n_sets; ++k) {
+    lgd_ctx::WorkSet &w = c->ws[k];
+    w.busy = false;
+    if ((rc = ensure(&w.d_E, &w.cap_E, c->total_e))) return rc;
+    if ((rc = ensure(&w.d_Z, &w.cap_Z, c->total_sb))) return rc;
+    if ((rc = ensure(&w.d_p1, &w.cap_p1, 4 * c->slices.size()))) return rc;
+    if ((rc = ensure(&w.d_p2, &w.cap_p2, 2 * c->slices.size()))) return rc;
+    if ((rc = ensure(&w.d_p2a, &w.cap_p2a, 2 * c->slices.size()))) return rc;
+    if ((rc = ensure(&w.d_st, &w.cap_st, c->total_st))) return rc;
+    if ((rc = ensure(&w.d_res, &w.cap_res, (size_t)n * LGR_STRIDE))) return rc;
+    if ((rc = ensure(&w.d_peaks, &w.cap_peaks, c->total_peak_floats))) return rc;
+    if ((rc = ensure(&w.d_segs, &w.cap_segs, c->segs.size()))) return rc;
+    if ((rc = ensure(&w.d_ranges, &w.cap_ranges, n))) return rc;
+    // the host descriptors hold offsets; each set gets its own pointers
+    std::vector<LgdSeg> segs(c->segs);
+    for (LgdSeg &sg : segs) {
+      sg.e_out = w.d_E + (uintptr_t)sg.e_out;
+      sg.peak_out = w.d_peaks + (uintptr_t)sg.peak_out;
+    }
+    for (uint32_t t = 0; t < n; ++t) {
+      c->ranges[t].off = c->meta[t].st_off;
+      c->ranges[t].n = c->meta[t].n_st_slots;
+      c->ranges[t].out = w.d_res + (size_t)t * LGR_STRIDE + LGR_LRA;
+    }
+    if (n)
+      HIPCHK(hipMemcpy(w.d_ranges, c->ranges.data(), n * sizeof(LgdRange), hipMemcpyHostToDevice));
+    if (!segs.empty())
+      HIPCHK(hipMemcpy(w.d_segs, segs.data(), segs.size() * sizeof(LgdSeg), hipMemcpyHostToDevice));
   }
-  if (n) {
+  if (n)
     HIPCHK(hipMemcpy(c->d_meta, c->meta.data(), n * sizeof(LgdTrackMeta), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(c->d_ranges, c->ranges.data(), n * sizeof(LgdRange), hipMemcpyHostToDevice));
-  }
-  if (!c->segs.empty())
-    HIPCHK(hipMemcpy(c->d_segs, c->segs.data(), c->segs.size() * sizeof(LgdSeg),
-                     hipMemcpyHostToDevice));
   if (!c->slices.empty())
     HIPCHK(hipMemcpy(c->d_slices, c->slices.data(), c->slices.size() * sizeof(LgdSlice),
                      hipMemcpyHostToDevice));
@@ -462,26 +503,32 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   return LGD_OK;
 }
 
+static int album_stage2_on(lgd_ctx *c, lgd_ctx::WorkSet &w, hipStream_t s) {
+  HIPCHK(lgd_launch_album_stage2(c->d_slices, (int)c->slices.size(), c->d_meta, w.d_Z, w.d_p1,
+                                 w.d_p2a, w.d_part1, w.d_part2, c->abs_gate, c->rel_factor, s));
+  return LGD_OK;
+}
+
+static int album_stage3_on(lgd_ctx *c, lgd_ctx::WorkSet &w, const double *st_all, uint64_t n_slots,
+                           hipStream_t s) {
+  HIPCHK(lgd_launch_album_final(w.d_part1, w.d_part2, c->rel_factor, w.d_album, s));
+  w.h_album_range->off = 0;
+  w.h_album_range->n = st_all ? (long long)n_slots : (long long)c->total_st;
+  w.h_album_range->out = w.d_album + 1;
+  HIPCHK(hipMemcpyAsync(w.d_album_range, w.h_album_range, sizeof(LgdRange), hipMemcpyHostToDevice, s));
+  HIPCHK(lgd_launch_lra(w.d_album_range, 1, st_all ? st_all : w.d_st, c->minus20, s));
+  return LGD_OK;
+}
+
 extern "C" int lgd_album_stage2(lgd_ctx *c, void *hip_stream) {
   if (!c || !c->planned || !c->executed) return fail(LGD_ESTATE, "album stage 2 before execute");
-  hipStream_t s = (hipStream_t)hip_stream;
-  HIPCHK(lgd_launch_album_stage2(c->d_slices, (int)c->slices.size(), c->d_meta, c->d_Z, c->d_p1,
-                                 c->d_p2a, c->d_part1, c->d_part2, c->abs_gate, c->rel_factor, s));
-  return LGD_OK;
+  return album_stage2_on(c, c->ws[c->cur_set], (hipStream_t)hip_stream);
 }
 
 extern "C" int lgd_album_stage3(lgd_ctx *c, const double *st_all, uint64_t n_slots,
                                 void *hip_stream) {
   if (!c || !c->planned || !c->executed) return fail(LGD_ESTATE, "album stage 3 before execute");
-  hipStream_t s = (hipStream_t)hip_stream;
-  HIPCHK(lgd_launch_album_final(c->d_part1, c->d_part2, c->rel_factor, c->d_album, s));
-  c->h_album_range->off = 0;
-  c->h_album_range->n = st_all ? (long long)n_slots : (long long)c->total_st;
-  c->h_album_range->out = c->d_album + 1;
-  HIPCHK(hipMemcpyAsync(c->d_album_range, c->h_album_range, sizeof(LgdRange),
-                        hipMemcpyHostToDevice, s));
-  HIPCHK(lgd_launch_lra(c->d_album_range, 1, st_all ? st_all : c->d_st, c->minus20, s));
-  return LGD_OK;
+  return album_stage3_on(c, c->ws[c->cur_set], st_all, n_slots, (hipStream_t)hip_stream);
 }
 
 extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
@@ -490,39 +537,63 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   hipStream_t s = (hipStream_t)hip_stream;
   const int n = (int)c->tracks.size();
   c->last_stream = s;
+  const int k = c->executed ? (c->cur_set + 1) % c->n_sets : 0;
+  lgd_ctx::WorkSet &w = c->ws[k];
+  c->cur_set = k;
+  // two sets: the epilogue goes to the side stream and overlaps the next scan
+  const bool overlap = c->n_sets == 2;
+  hipStream_t es = overlap ? c->side : s;
   hipEvent_t *ev = c->ev[c->n_exec % lgd_ctx::EV_RING];
+  if (overlap && w.busy) HIPCHK(hipStreamWaitEvent(s, w.ev_done, 0));  // set k is free again
   HIPCHK(hipEventRecord(ev[0], s));
   for (size_t gi = 0; gi < c->groups.size(); ++gi) {
     const Group &g = c->groups[gi];
-    HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, c->d_segs + g.seg_begin, (int)g.seg_count,
+    HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, w.d_segs + g.seg_begin, (int)g.seg_count,
                            c->d_filt + gi, s));
   }
   HIPCHK(hipEventRecord(ev[1], s));
-  HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, c->d_E, c->d_Z,
-                                   c->d_st, c->d_peaks, c->d_p1, c->d_p2, c->d_res, c->abs_gate,
-                                   c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
-  HIPCHK(lgd_launch_lra(c->d_ranges, n, c->d_st, c->minus20, s));
+  if (overlap) {
+    HIPCHK(hipEventRecord(w.ev_scan, s));
+    HIPCHK(hipStreamWaitEvent(es, w.ev_scan, 0));
+  }
+  HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, w.d_E, w.d_Z,
+                                   w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_res, c->abs_gate,
+                                   c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, es));
+  HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, es));
   c->executed = true;
   if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))
-    HIPCHK(lgd_launch_album_part1(c->d_res, n, c->d_part1, s));
+    HIPCHK(lgd_launch_album_part1(w.d_res, n, w.d_part1, es));
   if (c->flags & LGD_FLAG_ALBUM) {
     int rc;
-    if ((rc = lgd_album_stage2(c, hip_stream))) return rc;
-    if ((rc = lgd_album_stage3(c, nullptr, 0, hip_stream))) return rc;
+    if ((rc = album_stage2_on(c, w, es))) return rc;
+    if ((rc = album_stage3_on(c, w, nullptr, 0, es))) return rc;
   }
-  HIPCHK(hipEventRecord(ev[2], s));
+  HIPCHK(hipEventRecord(ev[2], es));
+  if (overlap) {
+    HIPCHK(hipEventRecord(w.ev_done, es));
+    w.busy = true;
+  }
   ++c->n_exec;
+  return LGD_OK;
+}
+
+// both streams of the last scans
+static int sync_all(lgd_ctx *c) {
+  HIPCHK(hipStreamSynchronize(c->last_stream));
+  if (c->n_sets == 2) HIPCHK(hipStreamSynchronize(c->side));
   return LGD_OK;
 }
 
 extern "C" int lgd_fetch(lgd_ctx *c, lgd_track_result *out, lgd_album_result *album) {
   if (!c || !c->executed) return fail(LGD_ESTATE, "lgd_fetch before lgd_execute");
   HIPCHK(hipSetDevice(c->device));
-  HIPCHK(hipStreamSynchronize(c->last_stream));
+  int rc;
+  if ((rc = sync_all(c))) return rc;
+  const lgd_ctx::WorkSet &w = c->ws[c->cur_set];
   const size_t n = c->tracks.size();
   if (n && out) {
     std::vector<double> r(n * LGR_STRIDE);
-    HIPCHK(hipMemcpy(r.data(), c->d_res, r.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r.data(), w.d_res, r.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t t = 0; t < n; ++t) {
       const double *p = &r[t * LGR_STRIDE];
       lgd_track_result &o = out[t];
@@ -545,7 +616,7 @@ extern "C" int lgd_fetch(lgd_ctx *c, lgd_track_result *out, lgd_album_result *al
     if (!(c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1)))
       return fail(LGD_ESTATE, "plan was made without an album flag");
     double a[9];
-    HIPCHK(hipMemcpy(a, c->d_album, sizeof(a), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(a, w.d_album, sizeof(a), hipMemcpyDeviceToHost));
     album->loudness = a[0];
     album->lra = a[1];
     album->peak = a[2];
@@ -561,18 +632,18 @@ extern "C" int lgd_fetch(lgd_ctx *c, lgd_track_result *out, lgd_album_result *al
 
 extern "C" int lgd_album_part1_ptr(lgd_ctx *c, lgd_album_part1 **p) {
   if (!c || !p) return fail(LGD_EINVAL, "null argument");
-  *p = (lgd_album_part1 *)c->d_part1;
+  *p = (lgd_album_part1 *)c->ws[0].d_part1;
   return LGD_OK;
 }
 extern "C" int lgd_album_part2_ptr(lgd_ctx *c, lgd_album_part2 **p) {
   if (!c || !p) return fail(LGD_EINVAL, "null argument");
-  *p = (lgd_album_part2 *)c->d_part2;
+  *p = (lgd_album_part2 *)c->ws[0].d_part2;
   return LGD_OK;
 }
 extern "C" int lgd_album_st_ptr(lgd_ctx *c, double **p, uint64_t *n_slots) {
   if (!c || !p || !n_slots) return fail(LGD_EINVAL, "null argument");
   if (!c->planned) return fail(LGD_ESTATE, "no plan");
-  *p = c->d_st;
+  *p = c->ws[0].d_st;
   *n_slots = c->total_st;
   return LGD_OK;
 }
@@ -581,14 +652,15 @@ extern "C" int lgd_copy_subblock_energies(lgd_ctx *c, uint32_t track, double *ho
                                           uint64_t cap, uint64_t *n_out) {
   if (!c || !c->executed) return fail(LGD_ESTATE, "no executed plan");
   if (track >= c->tracks.size()) return fail(LGD_EINVAL, "track index too high");
-  HIPCHK(hipStreamSynchronize(c->last_stream));
+  int rc;
+  if ((rc = sync_all(c))) return rc;
   const LgdTrackMeta &m = c->meta[track];
   const uint64_t n = std::min<uint64_t>(cap, (uint64_t)m.n_sb);
   if (n_out) *n_out = (uint64_t)m.n_sb;
   if (n && host_out) {
     // weighted channel sum, as the gating kernel forms it
     std::vector<double> tmp((size_t)m.n_sb * m.nch);
-    HIPCHK(hipMemcpy(tmp.data(), c->d_E + m.e_off, tmp.size() * sizeof(double),
+    HIPCHK(hipMemcpy(tmp.data(), c->ws[c->cur_set].d_E + m.e_off, tmp.size() * sizeof(double),
                      hipMemcpyDeviceToHost));
     for (uint64_t j = 0; j < n; ++j) {
       double s = 0.0;

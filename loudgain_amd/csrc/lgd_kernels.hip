@@ -90,7 +90,10 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 //     PO + f + floor(f / C) * PAD,   PO = HALO + PAD + (run-time alignment shift)
 template <int C, int G>
 struct LdsLayout {
-  static constexpr bool PLANAR = (G == 1 || G == 2);
+  // (stereo with odd C keeps the interleaved layout: its 2-way ds_read conflicts are
+  // invisible next to the fp64 work, and one ds_write_b128 per vector beats the
+  // 4 v_mov + 2 ds_write_b64 of the planar scatter)
+  static constexpr bool PLANAR = (G == 1) || (G == 2 && C % 2 == 0);
   static constexpr int PAD = (PLANAR && (C % 2 == 0)) ? 1 : 0;
   static constexpr int STRIDE = C + PAD;  // lane stride inside a plane
 };
@@ -151,9 +154,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
                inv_beta = F.inv_beta, dcg = F.dc, pb0sq = F.pb0sq;
   const int lps = F.lps;
   const int dbg = F.pad;  // measurement only: 1 = no global loads, 2 = no arithmetic
-  float tpc[K::NPH * K::NTAP + 1];
+  // interpolator coefficients, unique values only (the 49-tap prototype is
+  // symmetric: 4x phase 3 mirrors phase 1, phase 2 and the 2x phase mirror
+  // themselves) -> 18 / 12 SGPRs instead of 36 / 24
+  float tpa[12 + 1], tpb[6 + 1];
 #pragma unroll
-  for (int i = 0; i < K::NPH * K::NTAP; ++i) tpc[i] = F.tp[i];
+  for (int i = 0; i < (TP ? 12 : 0); ++i) tpa[i] = F.tp[i];
+#pragma unroll
+  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpb[i] = F.tp[12 + i];
 
   double cin[4] = {0.0, 0.0, 0.0, 0.0};  // wave-uniform filter state entering the tile
   double acc = 0.0;       // this lane's share of sub-block `cur`
@@ -358,20 +366,42 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
       nvalid = rem < 0 ? 0 : (rem > C ? C : (int)rem);
     }
     double e = 0.0;
-    // sample peak + (optionally) the polyphase interpolator of one window
-#define LGD_PEAKS(u_)                                                                   \
+    // sample peaks and the polyphase interpolator over one window of U frames:
+    // U x NPH independent accumulation chains, tap-major, so that neighbouring
+    // instructions never depend on each other and share the coefficient SGPR
+#define LGD_PEAKS_BLOCK()                                                               \
     do {                                                                                \
-      pk_s = fmaxf(pk_s, fabsf(w[HX + (u_)]));                                          \
-      if constexpr (TP != 0) {                                                          \
-        float m_ = 0.f;                                                                 \
-        _Pragma("unroll") for (int ph = 0; ph < K::NPH; ++ph) {                         \
-          float o_ = 0.f;                                                               \
-          _Pragma("unroll") for (int t2 = 0; t2 < K::NTAP; ++t2)                        \
-            o_ = fmaf(tpc[ph * K::NTAP + t2], w[HX + (u_) - t2], o_);                   \
-          m_ = fmaxf(m_, fabsf(o_));                                                    \
+      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) pk_s = fmaxf(pk_s, fabsf(w[HX + u_])); \
+      if constexpr (TP == 4) {                                                          \
+        float o1_[U], o2_[U], o3_[U];                                                   \
+        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) o1_[u_] = o2_[u_] = o3_[u_] = 0.f; \
+        _Pragma("unroll") for (int t_ = 0; t_ < 12; ++t_) {                             \
+          const float c1_ = tpa[t_], c3_ = tpa[11 - t_], c2_ = tpb[t_ < 6 ? t_ : 11 - t_]; \
+          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                            \
+            const float xv_ = w[HX + u_ - t_];                                          \
+            o1_[u_] = fmaf(c1_, xv_, o1_[u_]);                                          \
+            o2_[u_] = fmaf(c2_, xv_, o2_[u_]);                                          \
+            o3_[u_] = fmaf(c3_, xv_, o3_[u_]);                                          \
+          }                                                                             \
         }                                                                               \
-        if (tail) m_ = (j0 + (u_) < nvalid) ? m_ : 0.f;                                 \
-        pk_t = fmaxf(pk_t, m_);                                                         \
+        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                              \
+          float m_ = fmaxf(fmaxf(fabsf(o1_[u_]), fabsf(o2_[u_])), fabsf(o3_[u_]));      \
+          if (tail) m_ = (j0 + u_ < nvalid) ? m_ : 0.f;                                 \
+          pk_t = fmaxf(pk_t, m_);                                                       \
+        }                                                                               \
+      } else if constexpr (TP == 2) {                                                   \
+        float o1_[U];                                                                   \
+        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) o1_[u_] = 0.f;                 \
+        _Pragma("unroll") for (int t_ = 0; t_ < 24; ++t_) {                             \
+          const float c1_ = tpa[t_ < 12 ? t_ : 23 - t_];                                \
+          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                              \
+            o1_[u_] = fmaf(c1_, w[HX + u_ - t_], o1_[u_]);                              \
+        }                                                                               \
+        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                              \
+          float m_ = fabsf(o1_[u_]);                                                    \
+          if (tail) m_ = (j0 + u_ < nvalid) ? m_ : 0.f;                                 \
+          pk_t = fmaxf(pk_t, m_);                                                       \
+        }                                                                               \
       }                                                                                 \
     } while (0)
     if (filt) {
@@ -413,8 +443,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
           e = fma(y, y, e);
           qs[1] = qs[0]; qs[0] = q0;
           ps[1] = ps[0]; ps[0] = p0;
-          LGD_PEAKS(u);
         }
+        LGD_PEAKS_BLOCK();
         if constexpr (PIPE) {
 #pragma unroll
           for (int u = 0; u < U; ++u) w[HX + u] = xn[u];
@@ -427,11 +457,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         float w[U + HX];
 #pragma unroll
         for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
-#pragma unroll
-        for (int u = 0; u < U; ++u) LGD_PEAKS(u);
+        LGD_PEAKS_BLOCK();
       }
     }
-#undef LGD_PEAKS
+#undef LGD_PEAKS_BLOCK
 #undef LGD_X
 
     // ---- 100 ms sub-block sums: deterministic per-lane accumulate + wave tree
