@@ -120,16 +120,26 @@ static void design_scan_basis(LgdFilt &F, int chunk) {
   mat4_mul(T, Ac, M);
   mat4_mul(M, Ti, M);
   const ld TB[4] = {1, alr, gar, 0};  // T * (1, 0, 1, 0)
-  for (int i = 0; i < chunk; ++i) {
-    if (i == chunk - 2 || i == chunk - 1) {
-      double *g = F.g[i == chunk - 1 ? 0 : 1];  // g[0] = M^(C-1) T Bc, g[1] = M^(C-2) T Bc
-      for (int rr = 0; rr < 4; ++rr) {
-        ld acc = 0;
-        for (int c = 0; c < 4; ++c) acc += Mk[4 * rr + c] * TB[c];
-        g[rr] = (double)acc;
+  const int H1 = lgd_h1(chunk), H2 = chunk - H1;
+  // powers of M up to the chunk length; pick off what the kernel needs
+  for (int i = 0; i <= chunk; ++i) {
+    // Mk == M^i here.  A sub-chunk of length H: g[0] = M^(H-1) T Bc, g[1] = M^(H-2) T Bc
+    for (int which = 0; which < 2; ++which) {
+      const int H = which ? H2 : H1;
+      double (*g)[4] = which ? F.gH2 : F.gH1;
+      if (i == H - 1 || i == H - 2) {
+        for (int rr = 0; rr < 4; ++rr) {
+          ld acc = 0;
+          for (int c = 0; c < 4; ++c) acc += Mk[4 * rr + c] * TB[c];
+          g[i == H - 1 ? 0 : 1][rr] = (double)acc;
+        }
+      }
+      if (i == H) {
+        double *dst = which ? F.MH2 : F.MH1;
+        for (int e = 0; e < 16; ++e) dst[e] = (double)Mk[e];
       }
     }
-    mat4_mul(M, Mk, Mk);
+    if (i < chunk) mat4_mul(M, Mk, Mk);
   }
   for (int j = 0; j < 6; ++j) {
     for (int i = 0; i < 16; ++i) F.P[j][i] = (double)Mk[i];

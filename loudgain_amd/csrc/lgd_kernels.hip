@@ -108,8 +108,11 @@ struct ScanCfg {
   // 16-B vectors per thread and tile: ceil(((TILE_F + HALO) nch + 4) / 4 / (64 nch))
   static constexpr int NV = (16 * C + HALO / 4 + 1 + 63) / 64;
   // frames per streamed step: the largest divisor of C not above 8
-  static constexpr int U = (C % 8 == 0) ? 8 : (C % 7 == 0) ? 7 : (C % 6 == 0) ? 6 : (C % 5 == 0) ? 5
-                         : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : (C % 2 == 0) ? 2 : 1;
+  static constexpr int U = lgd_unroll(C);
+  // every lane's chunk is cut into two sub-chunks [0, H1) and [H1, C) that run as
+  // two independent, interleaved recurrences (ILP 2 per wave; H2 <= H1)
+  static constexpr int H1 = lgd_h1(C);
+  static constexpr int H2 = C - H1;
 };
 
 // (launch bounds: G waves per workgroup, >= 2 waves per SIMD wanted -> <= 256 VGPRs;
@@ -145,7 +148,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
   // for the fixed-channel-count kernels: no exec masking around full vectors)
 #define LGD_VEC_ALWAYS(i_) (G != 0 && (LGD_WAVE * G) * ((i_) + 1) <= (((K::TILE_F + K::HALO) * G + 4) >> 2))
   // floats per plane: HALO + shift slack + 64 padded chunks (+ tail slack), even
-  constexpr int PLANE = (K::HALO + 4 + LL::PAD + LGD_WAVE * LL::STRIDE + 4 + 1) & ~1;
+  // (+8: the software-pipelined reads fetch up to one step past the last chunk)
+  constexpr int PLANE = (K::HALO + 4 + LL::PAD + LGD_WAVE * LL::STRIDE + 4 + 8 + 1) & ~1;
   const bool filt = lgd_channel_weight(ch, nch) > 0.0;       // wave-uniform
 
   const double ra1 = F.ra[0], ra2 = F.ra[1], pa1 = F.pa[0], pa2 = F.pa[1];
@@ -186,10 +190,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
     pf_valid = (g0_ >= 0) && (g0_ + 4LL * nvec <= sg.n_floats); /* block-uniform */     \
     if (dbg & 1) pf_valid = false;                                                      \
     if (pf_valid) {                                                                     \
+      /* uniform base per vector (scalar adds) + one per-lane offset: no 64-bit    */   \
+      /* VALU address arithmetic, no per-load branches -> the loads stay batched   */   \
       const gvec_ptr src_ = (gvec_ptr)(sg.pcm + g0_);                                   \
       _Pragma("unroll") for (int i_ = 0; i_ < K::NV; ++i_) {                            \
-        const int idx_ = tid + nthreads * i_;                                           \
-        if ((LGD_VEC_ALWAYS(i_) || idx_ < nvec) && !(dbg & 32)) pf[i_] = src_[idx_];    \
+        const gvec_ptr src_i_ = src_ + nthreads * i_;                                   \
+        if (LGD_VEC_ALWAYS(i_) || tid + nthreads * i_ < nvec) pf[i_] = src_i_[tid];     \
       }                                                                                 \
     }                                                                                   \
   } while (0)
@@ -262,56 +268,103 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
     cfilt_ptr Fk = F0;
     asm volatile("" : "+s"(Fk));
     if (dbg & 2) continue;
-    double qs[2] = {0.0, 0.0}, ps[2] = {0.0, 0.0};
+    // start states of the two sub-chunks, as (q1, q2) and (p1, p2)
+    double qs[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, ps[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    constexpr int H1 = K::H1, H2 = K::H2;
     if (filt) {
-      // ---- A: zero-state run of q' = x/ra, p' = q'/pa over the chunk (4 FMAs per
-      // sample).  (1 - z^-1)^2 commutes with both, so second differences of the
-      // last four q', p' give the zero-state (q, p) at the chunk end; q', p' stay
-      // <= ~C^2 |x| here, so the differencing costs ~1e-13 |x| at most. --------
-      double z[4];
+      // ---- A: zero-state runs of q' = x/ra, p' = q'/pa over both sub-chunks (4 FMAs
+      // per sample and stream, the two streams interleaved).  (1 - z^-1)^2 commutes
+      // with both filters, so second differences of the last four q', p' give the
+      // zero-state (q, p) at a sub-chunk's end; q', p' stay <= ~C^2 |x| here, so
+      // the differencing costs ~1e-13 |x| at most. ---------------------------------
+      double z[4], z1[4];
       {
-        double qv[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0};
-        // LDS reads run one step ahead of the arithmetic (software pipeline)
-        float xa[U];
+        double qv[2][4], pv[2][4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) xa[u] = LGD_X(u);
-        // drain here, so that inside the loop the only LDS reads in flight are the
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qv[h][r] = pv[h][r] = 0.0;
+        // LDS reads run one step ahead of the arithmetic (software pipeline)
+        float xa[2][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          xa[0][u] = LGD_X(u);
+          xa[1][u] = LGD_X(H1 + u);
+        }
+        // drain here, so that inside the loops the only LDS reads in flight are the
         // NEXT step's (hipcc otherwise merges the pre-loop state into the loop and
         // waits for the reads it has just issued)
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#define LGD_A_STEP(h_, u_)                                                              \
+        do {                                                                            \
+          double t_ = fma(-ra2, qv[h_][1], (double)xa[h_][u_]);                         \
+          const double q0_ = fma(-ra1, qv[h_][0], t_);                                  \
+          t_ = fma(-pa2, pv[h_][1], q0_);                                               \
+          const double p0_ = fma(-pa1, pv[h_][0], t_);                                  \
+          qv[h_][3] = qv[h_][2]; qv[h_][2] = qv[h_][1]; qv[h_][1] = qv[h_][0]; qv[h_][0] = q0_; \
+          pv[h_][3] = pv[h_][2]; pv[h_][2] = pv[h_][1]; pv[h_][1] = pv[h_][0]; pv[h_][0] = p0_; \
+        } while (0)
+        const int a_end2 = (dbg & 4) ? 0 : H2, a_end1 = (dbg & 4) ? 0 : H1;
 #pragma unroll 1
-        for (int j0 = (dbg & 4) ? C : 0; j0 < C; j0 += U) {
-          float xn[U];
-          if (j0 + U < C) {
+        for (int j0 = 0; j0 < a_end2; j0 += U) {  // both streams
+          float xn[2][U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
+          for (int u = 0; u < U; ++u) {
+            xn[0][u] = LGD_X(j0 + U + u);  // (j0 + U < H1 always here, or H1 == H2 and unused)
+            xn[1][u] = LGD_X(H1 + j0 + U + u);
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            double t = fma(-ra2, qv[1], (double)xa[u]);
-            const double q0 = fma(-ra1, qv[0], t);
-            t = fma(-pa2, pv[1], q0);
-            const double p0 = fma(-pa1, pv[0], t);
-            qv[3] = qv[2]; qv[2] = qv[1]; qv[1] = qv[0]; qv[0] = q0;
-            pv[3] = pv[2]; pv[2] = pv[1]; pv[1] = pv[0]; pv[0] = p0;
+            LGD_A_STEP(0, u);
+            LGD_A_STEP(1, u);
           }
 #pragma unroll
-          for (int u = 0; u < U; ++u) xa[u] = xn[u];
+          for (int u = 0; u < U; ++u) {
+            xa[0][u] = xn[0][u];
+            xa[1][u] = xn[1][u];
+          }
         }
-        const double q1 = (qv[0] - 2.0 * qv[1]) + qv[2];
-        const double q2 = (qv[1] - 2.0 * qv[2]) + qv[3];
-        const double p1 = (pv[0] - 2.0 * pv[1]) + pv[2];
-        const double p2 = (pv[1] - 2.0 * pv[2]) + pv[3];
-        // the run assumed x[-1] = x[-2] = 0; the true history changes w[0] by
-        // -2x[-1] + x[-2] and w[1] by x[-1] (g = their effect on the end state)
-        const double xm1 = (double)LGD_X(-1), xm2 = (double)LGD_X(-2);
-        const double dw0 = fma(-2.0, xm1, xm2), dw1 = xm1;
-        double s0 = q1, s1 = alpha * fma(-beta, q2, q1), s2 = gamma_ * p1, s3 = gamma_ * p2;
-        s0 = fma(Fk->g[0][0], dw0, s0); s0 = fma(Fk->g[1][0], dw1, s0);
-        s1 = fma(Fk->g[0][1], dw0, s1); s1 = fma(Fk->g[1][1], dw1, s1);
-        s2 = fma(Fk->g[0][2], dw0, s2); s2 = fma(Fk->g[1][2], dw1, s2);
-        s3 = fma(Fk->g[0][3], dw0, s3); s3 = fma(Fk->g[1][3], dw1, s3);
-        z[0] = s0; z[1] = s1; z[2] = s2; z[3] = s3;
+#pragma unroll 1
+        for (int j0 = a_end2; j0 < a_end1; j0 += U) {  // the longer first sub-chunk alone
+          float xn[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
+#pragma unroll
+          for (int u = 0; u < U; ++u) LGD_A_STEP(0, u);
+#pragma unroll
+          for (int u = 0; u < U; ++u) xa[0][u] = xn[u];
+        }
+#undef LGD_A_STEP
+        // zero-state end states in the scan basis; the runs assumed a zero input
+        // history: the true x[-1], x[-2] in front of a sub-chunk change its w[0] by
+        // -2x[-1] + x[-2] and its w[1] by x[-1] (g = their effect on the end state)
+        double zz[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double q1 = (qv[h][0] - 2.0 * qv[h][1]) + qv[h][2];
+          const double q2 = (qv[h][1] - 2.0 * qv[h][2]) + qv[h][3];
+          const double p1 = (pv[h][0] - 2.0 * pv[h][1]) + pv[h][2];
+          const double p2 = (pv[h][1] - 2.0 * pv[h][2]) + pv[h][3];
+          const double xm1 = (double)(h ? LGD_X(H1 - 1) : LGD_X(-1));
+          const double xm2 = (double)(h ? LGD_X(H1 - 2) : LGD_X(-2));
+          const double dw0 = fma(-2.0, xm1, xm2), dw1 = xm1;
+          const auto *g0 = h ? Fk->gH2[0] : Fk->gH1[0];
+          const auto *g1 = h ? Fk->gH2[1] : Fk->gH1[1];
+          zz[h][0] = fma(g1[0], dw1, fma(g0[0], dw0, q1));
+          zz[h][1] = fma(g1[1], dw1, fma(g0[1], dw0, alpha * fma(-beta, q2, q1)));
+          zz[h][2] = fma(g1[2], dw1, fma(g0[2], dw0, gamma_ * p1));
+          zz[h][3] = fma(g1[3], dw1, fma(g0[3], dw0, gamma_ * p2));
+        }
+        // whole chunk: z = M^H2 z1 + z2 (block lower triangular transition)
+        {
+          const auto *P = Fk->MH2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z1[r] = zz[0][r];
+          z[0] = zz[1][0] + fma(P[1], z1[1], P[0] * z1[0]);
+          z[1] = zz[1][1] + fma(P[5], z1[1], P[4] * z1[0]);
+          z[2] = zz[1][2] + fma(P[11], z1[3], fma(P[10], z1[2], fma(P[9], z1[1], P[8] * z1[0])));
+          z[3] = zz[1][3] + fma(P[15], z1[3], fma(P[14], z1[2], fma(P[13], z1[1], P[12] * z1[0])));
+        }
       }
 
       // ---- B: inject the carry at lane 0, then Kogge-Stone over 64 lanes.  The
@@ -339,18 +392,29 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         }
       }
       // z is now the exact state at the END of each lane's chunk; the state at
-      // its START is the previous lane's (lane 0: the carry).  Back to (q, p).
-      double sv[4];
+      // its START is the previous lane's (lane 0: the carry); the second sub-chunk
+      // starts from M^H1 (start) + z1.  Back to (q, p).
+      double sv[2][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double up = __shfl_up(z[r], 1, LGD_WAVE);
-        sv[r] = (lane == 0) ? cin[r] : up;
+        sv[0][r] = (lane == 0) ? cin[r] : up;
         cin[r] = __shfl(z[r], LGD_WAVE - 1, LGD_WAVE);
       }
-      qs[0] = sv[0];
-      qs[1] = fma(-inv_alpha, sv[1], sv[0]) * inv_beta;
-      ps[0] = sv[2] * dcg;
-      ps[1] = sv[3] * dcg;
+      {
+        const auto *P = Fk->MH1;
+        sv[1][0] = z1[0] + fma(P[1], sv[0][1], P[0] * sv[0][0]);
+        sv[1][1] = z1[1] + fma(P[5], sv[0][1], P[4] * sv[0][0]);
+        sv[1][2] = z1[2] + fma(P[11], sv[0][3], fma(P[10], sv[0][2], fma(P[9], sv[0][1], P[8] * sv[0][0])));
+        sv[1][3] = z1[3] + fma(P[15], sv[0][3], fma(P[14], sv[0][2], fma(P[13], sv[0][1], P[12] * sv[0][0])));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        qs[h][0] = sv[h][0];
+        qs[h][1] = fma(-inv_alpha, sv[h][1], sv[h][0]) * inv_beta;
+        ps[h][0] = sv[h][2] * dcg;
+        ps[h][1] = sv[h][3] * dcg;
+      }
     }
 
     if (k < 0) continue;  // warm-up tile: only the carry matters
@@ -366,19 +430,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
       nvalid = rem < 0 ? 0 : (rem > C ? C : (int)rem);
     }
     double e = 0.0;
-    // sample peaks and the polyphase interpolator over one window of U frames:
-    // U x NPH independent accumulation chains, tap-major, so that neighbouring
-    // instructions never depend on each other and share the coefficient SGPR
-#define LGD_PEAKS_BLOCK()                                                               \
+    // sample peaks and the polyphase interpolator over one window `wv` of U frames
+    // starting at chunk frame jb: U x NPH independent accumulation chains, tap-major,
+    // so that neighbouring instructions never depend on each other and share the
+    // coefficient SGPR
+#define LGD_PEAKS_BLOCK(wv, jb)                                                         \
     do {                                                                                \
-      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) pk_s = fmaxf(pk_s, fabsf(w[HX + u_])); \
+      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) pk_s = fmaxf(pk_s, fabsf(wv[HX + u_])); \
       if constexpr (TP == 4) {                                                          \
         float o1_[U], o2_[U], o3_[U];                                                   \
         _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) o1_[u_] = o2_[u_] = o3_[u_] = 0.f; \
         _Pragma("unroll") for (int t_ = 0; t_ < 12; ++t_) {                             \
           const float c1_ = tpa[t_], c3_ = tpa[11 - t_], c2_ = tpb[t_ < 6 ? t_ : 11 - t_]; \
           _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                            \
-            const float xv_ = w[HX + u_ - t_];                                          \
+            const float xv_ = wv[HX + u_ - t_];                                         \
             o1_[u_] = fmaf(c1_, xv_, o1_[u_]);                                          \
             o2_[u_] = fmaf(c2_, xv_, o2_[u_]);                                          \
             o3_[u_] = fmaf(c3_, xv_, o3_[u_]);                                          \
@@ -386,7 +451,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         }                                                                               \
         _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                              \
           float m_ = fmaxf(fmaxf(fabsf(o1_[u_]), fabsf(o2_[u_])), fabsf(o3_[u_]));      \
-          if (tail) m_ = (j0 + u_ < nvalid) ? m_ : 0.f;                                 \
+          if (tail) m_ = ((jb) + u_ < nvalid) ? m_ : 0.f;                               \
           pk_t = fmaxf(pk_t, m_);                                                       \
         }                                                                               \
       } else if constexpr (TP == 2) {                                                   \
@@ -395,61 +460,101 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         _Pragma("unroll") for (int t_ = 0; t_ < 24; ++t_) {                             \
           const float c1_ = tpa[t_ < 12 ? t_ : 23 - t_];                                \
           _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                              \
-            o1_[u_] = fmaf(c1_, w[HX + u_ - t_], o1_[u_]);                              \
+            o1_[u_] = fmaf(c1_, wv[HX + u_ - t_], o1_[u_]);                             \
         }                                                                               \
         _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                              \
           float m_ = fabsf(o1_[u_]);                                                    \
-          if (tail) m_ = (j0 + u_ < nvalid) ? m_ : 0.f;                                 \
+          if (tail) m_ = ((jb) + u_ < nvalid) ? m_ : 0.f;                               \
           pk_t = fmaxf(pk_t, m_);                                                       \
         }                                                                               \
       }                                                                                 \
     } while (0)
     if (filt) {
-      double xh0 = (double)LGD_X(-1), xh1 = (double)LGD_X(-2);
-      float w[U + HX];  // frames j0-HX .. j0+U-1
+      // two interleaved streams: sub-chunk h covers chunk frames [h * H1, ...)
+      double xh[2][2], eh[2] = {0.0, 0.0};
+      xh[0][0] = (double)LGD_X(-1); xh[0][1] = (double)LGD_X(-2);
+      xh[1][0] = (double)LGD_X(H1 - 1); xh[1][1] = (double)LGD_X(H1 - 2);
+      float w[2][U + HX];  // per stream: frames j0-HX .. j0+U-1 of its sub-chunk
       // without the interpolator the next U frames are fetched a step ahead of
       // the arithmetic; with it the window is re-read per step (shifting an
       // 11..23-frame window through registers costs more than the LDS reads)
       constexpr bool PIPE = (TP == 0);
       if constexpr (PIPE) {
 #pragma unroll
-        for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(i - HX);
+        for (int i = 0; i < U + HX; ++i) {
+          w[0][i] = LGD_X(i - HX);
+          w[1][i] = LGD_X(H1 + i - HX);
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see phase A
       }
+#define LGD_C_STEP(h_, u_)                                                              \
+      do {                                                                              \
+        const double x_ = (double)w[h_][HX + (u_)];                                     \
+        double t_ = fma(-2.0, xh[h_][0], x_) + xh[h_][1]; /* w[n], exact */             \
+        xh[h_][1] = xh[h_][0];                                                          \
+        xh[h_][0] = x_;                                                                 \
+        t_ = fma(-ra2, qs[h_][1], t_);                                                  \
+        const double q0_ = fma(-ra1, qs[h_][0], t_);                                    \
+        t_ = fma(-pa2, ps[h_][1], q0_);                                                 \
+        const double p0_ = fma(-pa1, ps[h_][0], t_);                                    \
+        /* y / pb0 = p0 + (pb1/pb0) p1 + (pb2/pb0) p2; pb0^2 is applied per sub-block */ \
+        const double y_ = fma(c2, ps[h_][1], fma(c1, ps[h_][0], p0_));                  \
+        eh[h_] = fma(y_, y_, eh[h_]);                                                   \
+        qs[h_][1] = qs[h_][0]; qs[h_][0] = q0_;                                         \
+        ps[h_][1] = ps[h_][0]; ps[h_][0] = p0_;                                         \
+      } while (0)
+      const int c_end2 = (dbg & 16) ? 0 : H2, c_end1 = (dbg & 16) ? 0 : H1;
 #pragma unroll 1
-      for (int j0 = (dbg & 16) ? C : 0; j0 < C; j0 += U) {
-        float xn[U];
+      for (int j0 = 0; j0 < c_end2; j0 += U) {  // both streams
+        float xn[2][U];
         if constexpr (PIPE) {
-          if (j0 + U < C) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
+          for (int u = 0; u < U; ++u) {
+            xn[0][u] = LGD_X(j0 + U + u);
+            xn[1][u] = LGD_X(H1 + j0 + U + u);
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
+          for (int i = 0; i < U + HX; ++i) {
+            w[0][i] = LGD_X(j0 + i - HX);
+            w[1][i] = LGD_X(H1 + j0 + i - HX);
+          }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const double x = (double)w[HX + u];
-          double t = fma(-2.0, xh0, x) + xh1;  // w[n], exact
-          xh1 = xh0;
-          xh0 = x;
-          t = fma(-ra2, qs[1], t);
-          const double q0 = fma(-ra1, qs[0], t);
-          t = fma(-pa2, ps[1], q0);
-          const double p0 = fma(-pa1, ps[0], t);
-          // y / pb0 = p0 + (pb1/pb0) p1 + (pb2/pb0) p2; pb0^2 is applied per sub-block
-          const double y = fma(c2, ps[1], fma(c1, ps[0], p0));
-          e = fma(y, y, e);
-          qs[1] = qs[0]; qs[0] = q0;
-          ps[1] = ps[0]; ps[0] = p0;
+          LGD_C_STEP(0, u);
+          LGD_C_STEP(1, u);
         }
-        LGD_PEAKS_BLOCK();
+        LGD_PEAKS_BLOCK(w[0], j0);
+        LGD_PEAKS_BLOCK(w[1], H1 + j0);
         if constexpr (PIPE) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) w[HX + u] = xn[u];
+          for (int u = 0; u < U; ++u) {
+            w[0][HX + u] = xn[0][u];
+            w[1][HX + u] = xn[1][u];
+          }
         }
       }
+#pragma unroll 1
+      for (int j0 = c_end2; j0 < c_end1; j0 += U) {  // the longer first sub-chunk alone
+        float xn[U];
+        if constexpr (PIPE) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
+        } else {
+#pragma unroll
+          for (int i = 0; i < U + HX; ++i) w[0][i] = LGD_X(j0 + i - HX);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) LGD_C_STEP(0, u);
+        LGD_PEAKS_BLOCK(w[0], j0);
+        if constexpr (PIPE) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) w[0][HX + u] = xn[u];
+        }
+      }
+#undef LGD_C_STEP
+      e = eh[0] + eh[1];
     } else {
       // channel mapped EBUR128_UNUSED (e.g. LFE): no loudness, peaks only
 #pragma unroll 1
@@ -457,7 +562,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         float w[U + HX];
 #pragma unroll
         for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
-        LGD_PEAKS_BLOCK();
+        LGD_PEAKS_BLOCK(w, j0);
       }
     }
 #undef LGD_PEAKS_BLOCK
@@ -502,10 +607,11 @@ extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp) {
   const int halo = tp == 2 ? 24 : 12;
   if (nch <= 2) {
     const int pad = (chunk % 2 == 0) ? 1 : 0;
-    const int plane = (halo + 4 + pad + LGD_WAVE * (chunk + pad) + 4 + 1) & ~1;
+    const int plane = (halo + 4 + pad + LGD_WAVE * (chunk + pad) + 4 + 8 + 1) & ~1;
     return (size_t)nch * plane * sizeof(float);
   }
-  return ((size_t)(LGD_WAVE * chunk + halo) * nch + 4) * sizeof(float);
+  // (+8 frames: the software-pipelined reads fetch up to one step past the tile)
+  return ((size_t)(LGD_WAVE * chunk + halo + 8) * nch + 4) * sizeof(float);
 }
 
 template <int C, int G, int TP>
