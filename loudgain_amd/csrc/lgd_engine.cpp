@@ -141,8 +141,12 @@ static void design_scan_basis(LgdFilt &F, int chunk) {
     }
     if (i < chunk) mat4_mul(M, Mk, Mk);
   }
+  F.pskip = 0;
   for (int j = 0; j < 6; ++j) {
     for (int i = 0; i < 16; ++i) F.P[j][i] = (double)Mk[i];
+    // shelf-pole block negligible against double precision (the other entries are O(1))
+    const ld blk = std::max(std::max(fabsl(Mk[10]), fabsl(Mk[11])), std::max(fabsl(Mk[14]), fabsl(Mk[15])));
+    if (blk < 1e-19L) F.pskip |= 1 << j;
     mat4_mul(Mk, Mk, Mk);
   }
 }

@@ -40,7 +40,9 @@ struct LgdFilt {
                      // block lower triangular: P[.][2], [3], [6], [7] are zero)
   float tp[36];      // 4x: phases 1..3 x 12 taps; 2x: phase 1 x 24 taps (A.5)
   int lps;           // lanes (C-frame chunks) per 100 ms sub-block = s100 / C
-  int pad;
+  int pad;           // debug builds: floor-measurement mode bits
+  int pskip;         // bit j: P[j]'s shelf block (entries 10,11,14,15) is < 1e-19 -> skipped
+  int pad2;
 };
 
 // frames per streamed step of the scan kernel: the largest divisor of C not above 8

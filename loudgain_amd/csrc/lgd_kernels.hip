@@ -157,7 +157,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
   const double alpha = F.alpha, beta = F.beta, gamma_ = F.gamma, inv_alpha = F.inv_alpha,
                inv_beta = F.inv_beta, dcg = F.dc, pb0sq = F.pb0sq;
   const int lps = F.lps;
-  const int dbg = F.pad;  // measurement only: 1 = no global loads, 2 = no arithmetic
+  const int pskip = F.pskip;
+  // floor-measurement modes: 1 no global loads, 2 no arithmetic,
+  // 4/8/16 skip phase A / the scan / phase C, 64 loads issued but never staged.
+  // Compiled in only with -DLGD_DEBUG_MODES (make DEBUG_MODES=1).
+#ifdef LGD_DEBUG_MODES
+  const int dbg = F.pad;
+#else
+  constexpr int dbg = 0;
+#endif
   // interpolator coefficients, unique values only (the 49-tap prototype is
   // symmetric: 4x phase 3 mirrors phase 1, phase 2 and the 2x phase mirror
   // themselves) -> 18 / 12 SGPRs instead of 36 / 24
@@ -305,8 +313,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
           pv[h_][3] = pv[h_][2]; pv[h_][2] = pv[h_][1]; pv[h_][1] = pv[h_][0]; pv[h_][0] = p0_; \
         } while (0)
         const int a_end2 = (dbg & 4) ? 0 : H2, a_end1 = (dbg & 4) ? 0 : H1;
-#pragma unroll 1
-        for (int j0 = 0; j0 < a_end2; j0 += U) {  // both streams
+#pragma unroll 2
+        for (int j0 = 0; j0 < a_end2; j0 += U) {  // both streams (x2: the register copies of the read pipeline fold away)
           float xn[2][U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
@@ -381,14 +389,29 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         if (dbg & 8) break;
         const int d = 1 << s;
         const auto *P = Fk->P[s];
+        // once the span C * 2^s exceeds the memory of the shelf poles (radius
+        // ~0.85: < 1e-19 after ~300 frames) their own 2x2 block of the transition
+        // is zero to double precision: those steps move and multiply half as much
+        const bool shelf = !((pskip >> s) & 1);  // wave-uniform
         double u[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) u[c] = __shfl_up(z[c], d, LGD_WAVE);
+        u[0] = __shfl_up(z[0], d, LGD_WAVE);
+        u[1] = __shfl_up(z[1], d, LGD_WAVE);
+        if (shelf) {
+          u[2] = __shfl_up(z[2], d, LGD_WAVE);
+          u[3] = __shfl_up(z[3], d, LGD_WAVE);
+        } else {
+          u[2] = u[3] = 0.0;
+        }
         if (lane >= d) {  // exec-masked, no cross-lane traffic inside
           z[0] += fma(P[1], u[1], P[0] * u[0]);
           z[1] += fma(P[5], u[1], P[4] * u[0]);
-          z[2] += fma(P[11], u[3], fma(P[10], u[2], fma(P[9], u[1], P[8] * u[0])));
-          z[3] += fma(P[15], u[3], fma(P[14], u[2], fma(P[13], u[1], P[12] * u[0])));
+          double t2 = fma(P[9], u[1], P[8] * u[0]), t3 = fma(P[13], u[1], P[12] * u[0]);
+          if (shelf) {
+            t2 = fma(P[11], u[3], fma(P[10], u[2], t2));
+            t3 = fma(P[15], u[3], fma(P[14], u[2], t3));
+          }
+          z[2] += t2;
+          z[3] += t3;
         }
       }
       // z is now the exact state at the END of each lane's chunk; the state at
@@ -504,7 +527,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         ps[h_][1] = ps[h_][0]; ps[h_][0] = p0_;                                         \
       } while (0)
       const int c_end2 = (dbg & 16) ? 0 : H2, c_end1 = (dbg & 16) ? 0 : H1;
-#pragma unroll 1
+#pragma unroll 2
       for (int j0 = 0; j0 < c_end2; j0 += U) {  // both streams
         float xn[2][U];
         if constexpr (PIPE) {
