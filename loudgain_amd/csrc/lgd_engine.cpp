@@ -21,9 +21,9 @@
 #include "lgd_internal.h"
 
 extern "C" const int lgd_chunk_table[];
-extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp);
-extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
-                                      const LgdFilt *F, hipStream_t s);
+extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic);
+extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, const LgdSeg *segs,
+                                      int n_seg, const LgdFilt *F, hipStream_t s);
 extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_slices,
                                                 const LgdTrackMeta *meta, int n_tracks,
                                                 const double *E, double *Z, double *st,
@@ -186,12 +186,14 @@ static void design_interp(int factor, float tp[36]) {
 
 // ------------------------------------------------------------------ context --
 struct Group {  // tracks sharing (rate, channels) -> one scan launch
-  unsigned rate, nch;
+  unsigned rate, nch, nch_total;  // nch: channels (waves) per workgroup
   int chunk, tp;
+  bool generic;
   LgdFilt F;
   size_t seg_begin, seg_count;
 };
 static const size_t MAX_GROUPS = 64;  // distinct (rate, channels) pairs per plan
+static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at most
 
 struct lgd_ctx {
   int device = 0;
@@ -333,7 +335,7 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   const size_t lds_cap = 160 * 1024;  // per CU == per workgroup limit on gfx950
   if (forced) {
     for (const int *p = lgd_chunk_table; *p; ++p)
-      if (*p == forced && s100 % *p == 0 && lgd_scan_lds_bytes(*p, (int)nch, tp) <= lds_cap)
+      if (*p == forced && s100 % *p == 0 && lgd_scan_lds_bytes(*p, (int)nch, tp, nch > 2) <= lds_cap)
         return *p;
     return 0;
   }
@@ -346,7 +348,7 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   const int *pref = nch <= 2 ? pref_fast : pref_many;
   for (int pass = 0; pass < 2; ++pass)
     for (const int *p = pref; *p; ++p)
-      if (s100 % *p == 0 && lgd_scan_lds_bytes(*p, (int)nch, tp) <= (pass ? lds_cap : lds_cap / 4))
+      if (s100 % *p == 0 && lgd_scan_lds_bytes(*p, (int)nch, tp, nch > 2) <= (pass ? lds_cap : lds_cap / 4))
         return *p;
   return 0;
 }
@@ -375,9 +377,6 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     if (tr.frames && !tr.pcm) return fail(LGD_EINVAL, "track %u: null PCM pointer", t);
     if (((uintptr_t)tr.pcm) & 15)
       return fail(LGD_EINVAL, "track %u: PCM pointer must be 16-byte aligned", t);
-    if (tr.channels > 16)
-      return fail(LGD_EUNSUP, "track %u: %u channels (the kernels cover 1..16 so far)", t,
-                  tr.channels);
     LgdTrackMeta &m = c->meta[t];
     m.s100 = (int)((tr.rate + 5) / 10);
     m.nch = (int)tr.channels;
@@ -397,9 +396,17 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     c->pcm_bytes += tr.frames * tr.channels * 4ull;
   }
 
-  // group tracks by (rate, channels)
-  std::map<std::pair<unsigned, unsigned>, std::vector<uint32_t>> by_cfg;
-  for (uint32_t t = 0; t < n; ++t) by_cfg[{tracks[t].rate, tracks[t].channels}].push_back(t);
+  // launch groups: tracks (or 16-channel groups of wide tracks) that share
+  // (rate, channels of the stream, channels per workgroup) run in one launch
+  struct Key {
+    unsigned rate, nch_total, g_nch;
+    bool operator<(const Key &o) const {
+      return rate != o.rate ? rate < o.rate
+                            : (nch_total != o.nch_total ? nch_total < o.nch_total : g_nch < o.g_nch);
+    }
+  };
+  std::map<Key, size_t> group_of;
+  std::vector<std::vector<LgdSeg>> group_segs;
 
   // segment length: spread all sub-blocks over ~waves_per_cu waves per CU
   // (one wave per segment and channel: total_e counts sub-blocks x channels)
@@ -410,60 +417,81 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   if (!c->p_seg_sb && seg_sb < min_seg) seg_sb = min_seg;  // keep the warm-up overhead bounded
   if (seg_sb < 1) seg_sb = 1;
 
-  for (auto &kv : by_cfg) {
-    Group g;
-    g.rate = kv.first.first;
-    g.nch = kv.first.second;
-    const int s100 = (int)((g.rate + 5) / 10);
-    g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
-    g.chunk = pick_chunk(c->p_chunk, s100, g.nch, g.tp);
-    if (!g.chunk)
-      return fail(LGD_EUNSUP,
-                  "no compiled chunk length divides the %d-frame sub-block of %u Hz and fits LDS "
-                  "with %u channels", s100, g.rate, g.nch);
-    memset(&g.F, 0, sizeof(g.F));
-    design_kfilter((double)g.rate, g.F.pb, g.F.pa, g.F.ra);
-    design_scan_basis(g.F, g.chunk);
-    design_interp(g.tp, g.F.tp);
-    g.F.pbn[0] = g.F.pb[1] / g.F.pb[0];
-    g.F.pbn[1] = g.F.pb[2] / g.F.pb[0];
-    g.F.pb0sq = g.F.pb[0] * g.F.pb[0];
-    g.F.lps = s100 / g.chunk;
-    g.F.pad = (int)c->p_debug;
-    g.seg_begin = c->segs.size();
-    const long long tile_f = 64LL * g.chunk;
-    const int warm_tiles =
-        c->p_warm_sb ? (int)(((long long)c->p_warm_sb * s100 + tile_f - 1) / tile_f) : 0;
-    for (uint32_t t : kv.second) {
-      const lgd_track &tr = tracks[t];
-      LgdTrackMeta &m = c->meta[t];
-      const uint64_t nsb = (uint64_t)m.n_sb;
-      uint64_t nseg = nsb ? (nsb + seg_sb - 1) / seg_sb : 1;
-      m.n_seg = (int)nseg;
-      m.peak_off = (long long)c->total_peak_floats;
-      c->total_peak_floats += nseg * 2ull * tr.channels;
+  for (uint32_t t = 0; t < n; ++t) {
+    const lgd_track &tr = tracks[t];
+    LgdTrackMeta &m = c->meta[t];
+    const int s100 = m.s100;
+    const uint64_t nsb = (uint64_t)m.n_sb;
+    const uint64_t nseg = nsb ? (nsb + seg_sb - 1) / seg_sb : 1;
+    m.n_seg = (int)nseg;
+    m.peak_off = (long long)c->total_peak_floats;
+    c->total_peak_floats += nseg * 2ull * tr.channels;
+    for (unsigned ch0 = 0; ch0 < tr.channels; ch0 += LGD_GROUP_CH) {
+      const unsigned g_nch = std::min<unsigned>(LGD_GROUP_CH, tr.channels - ch0);
+      const Key key{tr.rate, tr.channels, g_nch};
+      auto it = group_of.find(key);
+      if (it == group_of.end()) {
+        Group g;
+        g.rate = tr.rate;
+        g.nch = g_nch;
+        g.nch_total = tr.channels;
+        g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
+        g.chunk = g_nch <= 2 ? pick_chunk(c->p_chunk, s100, g_nch, g.tp) : 0;
+        // fast kernels: mono / stereo with a chunk that divides the sub-block; anything else
+        // (more channels, channel groups, rates such as 11 025 Hz) goes to the generic kernel,
+        // where sub-block boundaries may fall inside a chunk
+        g.generic = g_nch > 2 || !g.chunk;
+        if (g.generic) g.chunk = 25;
+        // below ~3.4 kHz the shelf's 1682 Hz corner lies beyond Nyquist and the
+        // reference's own filter design is meaningless (it yields inf/NaN loudness)
+        if (tr.rate < 4000)
+          return fail(LGD_EUNSUP, "track %u: sample rate %u Hz is below the 4 kHz floor", t, tr.rate);
+        memset(&g.F, 0, sizeof(g.F));
+        design_kfilter((double)g.rate, g.F.pb, g.F.pa, g.F.ra);
+        design_scan_basis(g.F, g.chunk);
+        design_interp(g.tp, g.F.tp);
+        g.F.pbn[0] = g.F.pb[1] / g.F.pb[0];
+        g.F.pbn[1] = g.F.pb[2] / g.F.pb[0];
+        g.F.pb0sq = g.F.pb[0] * g.F.pb[0];
+        g.F.lps = s100 / g.chunk;
+        g.F.s100 = s100;
+        g.F.pad = (int)c->p_debug;
+        g.seg_begin = g.seg_count = 0;
+        it = group_of.emplace(key, c->groups.size()).first;
+        c->groups.push_back(g);
+        group_segs.emplace_back();
+      }
+      const Group &g = c->groups[it->second];
+      const long long tile_f = 64LL * g.chunk;
+      const int warm_tiles =
+          c->p_warm_sb ? (int)(((long long)c->p_warm_sb * s100 + tile_f - 1) / tile_f) : 0;
       uint64_t sb0 = 0;
-      for (uint64_t s = 0; s < nseg; ++s) {
-        const uint64_t cnt = nsb / nseg + (s < nsb % nseg ? 1 : 0);
+      for (uint64_t sgi = 0; sgi < nseg; ++sgi) {
+        const uint64_t cnt = nsb / nseg + (sgi < nsb % nseg ? 1 : 0);
         LgdSeg sg;
         sg.pcm = tr.pcm;
         sg.n_floats = (long long)(tr.frames * tr.channels);
         sg.f0 = (long long)(sb0 * (uint64_t)s100);
         sg.n_sb = (int)cnt;
-        sg.f_peak_end = (s + 1 == nseg) ? (long long)tr.frames : (long long)((sb0 + cnt) * s100);
+        sg.f_peak_end = (sgi + 1 == nseg) ? (long long)tr.frames : (long long)((sb0 + cnt) * s100);
         sg.n_warm_tiles = sb0 ? warm_tiles : 0;
         // offsets are patched to pointers once the workspace exists
         sg.e_out = (double *)(uintptr_t)(m.e_off + (long long)sb0);
         sg.e_ch_stride = m.n_sb;
+        sg.ch0 = (int)ch0;
+        sg.nch_total = (int)tr.channels;
         sg.pad = 0;
-        sg.peak_out = (float *)(uintptr_t)(m.peak_off + (long long)(s * 2ull * tr.channels));
-        c->segs.push_back(sg);
-        if (sb0) c->warm_bytes += (uint64_t)warm_tiles * tile_f * tr.channels * 4ull;
+        sg.peak_out = (float *)(uintptr_t)(m.peak_off + (long long)(sgi * 2ull * tr.channels));
+        group_segs[it->second].push_back(sg);
+        if (sb0) c->warm_bytes += (uint64_t)warm_tiles * tile_f * g_nch * 4ull;
         sb0 += cnt;
       }
     }
-    g.seg_count = c->segs.size() - g.seg_begin;
-    c->groups.push_back(g);
+  }
+  for (size_t gi = 0; gi < c->groups.size(); ++gi) {
+    c->groups[gi].seg_begin = c->segs.size();
+    c->groups[gi].seg_count = group_segs[gi].size();
+    c->segs.insert(c->segs.end(), group_segs[gi].begin(), group_segs[gi].end());
   }
 
   // the caller-driven (multi-GPU) album keeps one set: its partial pointers are
@@ -562,8 +590,8 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   HIPCHK(hipEventRecord(ev[0], s));
   for (size_t gi = 0; gi < c->groups.size(); ++gi) {
     const Group &g = c->groups[gi];
-    HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, w.d_segs + g.seg_begin, (int)g.seg_count,
-                           c->d_filt + gi, s));
+    HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, g.generic ? 1 : 0, w.d_segs + g.seg_begin,
+                           (int)g.seg_count, c->d_filt + gi, s));
   }
   HIPCHK(hipEventRecord(ev[1], s));
   if (overlap) {

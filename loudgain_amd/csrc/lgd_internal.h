@@ -17,6 +17,8 @@ struct LgdSeg {
   int n_sb;              // whole sub-blocks in this segment
   int n_warm_tiles;      // K-filter warm-up tiles run before f0 (0 at track start)
   int e_ch_stride;       // whole sub-blocks of the track (channel stride in E)
+  int ch0;               // first channel this workgroup handles (channel groups of
+  int nch_total;         // streams with > 16 channels; otherwise 0 and the channel count)
   int pad;
 };
 
@@ -42,7 +44,7 @@ struct LgdFilt {
   int lps;           // lanes (C-frame chunks) per 100 ms sub-block = s100 / C
   int pad;           // debug builds: floor-measurement mode bits
   int pskip;         // bit j: P[j]'s shelf block (entries 10,11,14,15) is < 1e-19 -> skipped
-  int pad2;
+  int s100;          // frames per 100 ms sub-block (generic kernel: any alignment)
 };
 
 // frames per streamed step of the scan kernel: the largest divisor of C not above 8

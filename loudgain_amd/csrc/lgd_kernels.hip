@@ -120,9 +120,12 @@ struct ScanCfg {
 // short chunks)
 // The interpolator variants are pinned to exactly 2 waves per SIMD: left alone,
 // hipcc aims for 3 and spills the FIR window to scratch.
-template <int C, int G, int TP>
-__global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ? LGD_WAVE * G : 1024),
-                          amdgpu_waves_per_eu(G ? 2 : 4, (G && TP) ? 2 : 4))) void lgd_scan_kernel(
+// WIDE (run-time-G kernel only): up to 16 waves per workgroup -> <= 128 VGPRs;
+// otherwise up to 8 waves (<= 256 VGPRs, no spills).
+template <int C, int G, int TP, bool WIDE = false>
+__global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
+                                                      G ? LGD_WAVE * G : (WIDE ? 1024 : 512)),
+                          amdgpu_waves_per_eu(G ? 2 : (WIDE ? 4 : 2), (G && TP) ? 2 : 4))) void lgd_scan_kernel(
     const LgdSeg *__restrict__ segs, const LgdFilt *__restrict__ Fg, const int nch_rt) {
   using K = ScanCfg<C, TP>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -140,8 +143,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
   const int ch = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = LGD_WAVE * nch;
   const LgdSeg sg = segs[blockIdx.x];
-  const int shift = (int)((sg.f0 * nch) & 3);
-  const long long n_frames = sg.n_floats / nch;
+  const int shift = (G == 0 && sg.nch_total != (G ? G : nch_rt)) ? 0 : (int)((sg.f0 * nch) & 3);
+  const long long n_frames = sg.n_floats / (G ? G : sg.nch_total);
   const int nvec = ((K::TILE_F + K::HALO) * nch + 4) >> 2;  // 16-B vectors per tile
   using LL = LdsLayout<C, G>;
   // vector i of a thread is in range for EVERY thread when this holds (compile-time
@@ -150,7 +153,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
   // floats per plane: HALO + shift slack + 64 padded chunks (+ tail slack), even
   // (+8: the software-pipelined reads fetch up to one step past the last chunk)
   constexpr int PLANE = (K::HALO + 4 + LL::PAD + LGD_WAVE * LL::STRIDE + 4 + 8 + 1) & ~1;
-  const bool filt = lgd_channel_weight(ch, nch) > 0.0;       // wave-uniform
+  // channel groups (streams with more than 16 channels, run-time-G kernel only):
+  // this workgroup handles channels [ch0, ch0 + nch) of an nch_tot-channel stream
+  const int ch0 = G ? 0 : sg.ch0;
+  const int nch_tot = G ? G : sg.nch_total;
+  const bool grouped = (G == 0) && (nch_tot != nch);
+  const bool filt = lgd_channel_weight(ch0 + ch, nch_tot) > 0.0;  // wave-uniform
 
   const double ra1 = F.ra[0], ra2 = F.ra[1], pa1 = F.pa[0], pa2 = F.pa[1];
   const double c1 = F.pbn[0], c2 = F.pbn[1];
@@ -158,6 +166,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
                inv_beta = F.inv_beta, dcg = F.dc, pb0sq = F.pb0sq;
   const int lps = F.lps;
   const int pskip = F.pskip;
+  const int s100 = F.s100;
   // floor-measurement modes: 1 no global loads, 2 no arithmetic,
   // 4/8/16 skip phase A / the scan / phase C, 64 loads issued but never staged.
   // Compiled in only with -DLGD_DEBUG_MODES (make DEBUG_MODES=1).
@@ -195,7 +204,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
 #define LGD_PREFETCH(kk)                                                                \
   do {                                                                                  \
     const long long g0_ = LGD_TILE_G0(kk); /* float index of lds[0], multiple of 4 */   \
-    pf_valid = (g0_ >= 0) && (g0_ + 4LL * nvec <= sg.n_floats); /* block-uniform */     \
+    pf_valid = (g0_ >= 0) && (g0_ + 4LL * nvec <= sg.n_floats) && !grouped; /* uniform */ \
     if (dbg & 1) pf_valid = false;                                                      \
     if (pf_valid) {                                                                     \
       /* uniform base per vector (scalar adds) + one per-lane offset: no 64-bit    */   \
@@ -239,6 +248,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
       for (int i = 0; i < K::NV; ++i) {
         const int idx = tid + nthreads * i;
         if (LGD_VEC_ALWAYS(i) || idx < nvec) LGD_STORE_VEC(idx, pf[i]);
+      }
+    } else if (grouped) {
+      // a channel group of a wide stream: gather [frame][ch0 .. ch0 + nch) float by float
+      const gflt_ptr gp = (gflt_ptr)sg.pcm;
+      const int nfl = (K::TILE_F + K::HALO) * nch;
+      for (int i = tid; i < nfl; i += nthreads) {
+        const int fr = i / nch, c = i - fr * nch;
+        const long long f = tb - K::HALO + fr;
+        lds[i] = (f >= 0 && f < n_frames) ? gp[f * nch_tot + ch0 + c] : 0.f;
       }
     } else if (!(dbg & 1) && !(dbg & 64)) {
       const long long g0 = LGD_TILE_G0(k);
@@ -452,7 +470,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
       const long long rem = n_frames - lane_f;
       nvalid = rem < 0 ? 0 : (rem > C ? C : (int)rem);
     }
-    double e = 0.0;
+    double e = 0.0, e_next = 0.0;  // e_next: generic kernel, frames past a sub-block boundary
+    // generic (run-time channel count) kernel: the chunk length need not divide the
+    // sub-block length; frames j < bnd of this chunk belong to sub-block sb_l, the
+    // rest to sb_l + 1 (at most one boundary per chunk: C <= s100)
+    int sb_l = 0, bnd = C;
+    if constexpr (G == 0) {
+      const unsigned fl = (unsigned)k * K::TILE_F + (unsigned)lane * C;  // chunk start, relative to f0
+      sb_l = (int)(fl / (unsigned)s100);
+      const unsigned rem = (unsigned)(sb_l + 1) * (unsigned)s100 - fl;
+      bnd = rem < (unsigned)C ? (int)rem : C;
+    }
     // sample peaks and the polyphase interpolator over one window `wv` of U frames
     // starting at chunk frame jb: U x NPH independent accumulation chains, tap-major,
     // so that neighbouring instructions never depend on each other and share the
@@ -494,7 +522,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
     } while (0)
     if (filt) {
       // two interleaved streams: sub-chunk h covers chunk frames [h * H1, ...)
-      double xh[2][2], eh[2] = {0.0, 0.0};
+      double xh[2][2], eh[2] = {0.0, 0.0}, en[2] = {0.0, 0.0};
       xh[0][0] = (double)LGD_X(-1); xh[0][1] = (double)LGD_X(-2);
       xh[1][0] = (double)LGD_X(H1 - 1); xh[1][1] = (double)LGD_X(H1 - 2);
       float w[2][U + HX];  // per stream: frames j0-HX .. j0+U-1 of its sub-chunk
@@ -510,7 +538,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see phase A
       }
-#define LGD_C_STEP(h_, u_)                                                              \
+#define LGD_C_STEP(h_, u_, jc_)                                                         \
       do {                                                                              \
         const double x_ = (double)w[h_][HX + (u_)];                                     \
         double t_ = fma(-2.0, xh[h_][0], x_) + xh[h_][1]; /* w[n], exact */             \
@@ -522,7 +550,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         const double p0_ = fma(-pa1, ps[h_][0], t_);                                    \
         /* y / pb0 = p0 + (pb1/pb0) p1 + (pb2/pb0) p2; pb0^2 is applied per sub-block */ \
         const double y_ = fma(c2, ps[h_][1], fma(c1, ps[h_][0], p0_));                  \
-        eh[h_] = fma(y_, y_, eh[h_]);                                                   \
+        if constexpr (G == 0) {                                                         \
+          const double y2_ = y_ * y_;                                                   \
+          const bool lo_ = (jc_) < bnd;                                                 \
+          eh[h_] += lo_ ? y2_ : 0.0;                                                    \
+          en[h_] += lo_ ? 0.0 : y2_;                                                    \
+        } else {                                                                        \
+          eh[h_] = fma(y_, y_, eh[h_]);                                                 \
+        }                                                                               \
         qs[h_][1] = qs[h_][0]; qs[h_][0] = q0_;                                         \
         ps[h_][1] = ps[h_][0]; ps[h_][0] = p0_;                                         \
       } while (0)
@@ -545,8 +580,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          LGD_C_STEP(0, u);
-          LGD_C_STEP(1, u);
+          LGD_C_STEP(0, u, j0 + u);
+          LGD_C_STEP(1, u, H1 + j0 + u);
         }
         LGD_PEAKS_BLOCK(w[0], j0);
         LGD_PEAKS_BLOCK(w[1], H1 + j0);
@@ -569,7 +604,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
           for (int i = 0; i < U + HX; ++i) w[0][i] = LGD_X(j0 + i - HX);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) LGD_C_STEP(0, u);
+        for (int u = 0; u < U; ++u) LGD_C_STEP(0, u, j0 + u);
         LGD_PEAKS_BLOCK(w[0], j0);
         if constexpr (PIPE) {
 #pragma unroll
@@ -578,6 +613,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
       }
 #undef LGD_C_STEP
       e = eh[0] + eh[1];
+      e_next = en[0] + en[1];
     } else {
       // channel mapped EBUR128_UNUSED (e.g. LFE): no loudness, peaks only
 #pragma unroll 1
@@ -593,20 +629,37 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
 
     // ---- 100 ms sub-block sums: deterministic per-lane accumulate + wave tree
     if (filt) {
-      int rel = k * LGD_WAVE + lane - cur_q;  // (the host keeps tiles per segment < 2^24)
-      for (;;) {
-        const bool mine = rel >= 0 && rel < lps;
-        acc += mine ? e : 0.0;
-        if (k * LGD_WAVE + LGD_WAVE >= cur_q + lps) {  // `cur` ends in this tile
-          const double tot = wave_sum_f64(acc) * pb0sq;
-          if (lane == 0 && cur < sg.n_sb)
-            ((double LGD_GLOBAL *)sg.e_out)[(long long)ch * sg.e_ch_stride + cur] = tot;
-          acc = 0.0;
-          ++cur;
-          cur_q += lps;
-          rel -= lps;
-        } else {
-          break;
+      if constexpr (G != 0) {
+        int rel = k * LGD_WAVE + lane - cur_q;  // (the host keeps tiles per segment < 2^24)
+        for (;;) {
+          const bool mine = rel >= 0 && rel < lps;
+          acc += mine ? e : 0.0;
+          if (k * LGD_WAVE + LGD_WAVE >= cur_q + lps) {  // `cur` ends in this tile
+            const double tot = wave_sum_f64(acc) * pb0sq;
+            if (lane == 0 && cur < sg.n_sb)
+              ((double LGD_GLOBAL *)sg.e_out)[(long long)ch * sg.e_ch_stride + cur] = tot;
+            acc = 0.0;
+            ++cur;
+            cur_q += lps;
+            rel -= lps;
+          } else {
+            break;
+          }
+        }
+      } else {
+        // generic: sub-block boundaries anywhere (also inside a chunk)
+        const unsigned tile_end = (unsigned)(k + 1) * K::TILE_F;  // relative to f0
+        for (;;) {
+          acc += (sb_l == cur ? e : 0.0) + (sb_l + 1 == cur ? e_next : 0.0);
+          if (tile_end >= (unsigned)(cur + 1) * (unsigned)s100) {  // `cur` ends in this tile
+            const double tot = wave_sum_f64(acc) * pb0sq;
+            if (lane == 0 && cur < sg.n_sb)
+              ((double LGD_GLOBAL *)sg.e_out)[(long long)(ch0 + ch) * sg.e_ch_stride + cur] = tot;
+            acc = 0.0;
+            ++cur;
+          } else {
+            break;
+          }
         }
       }
     }
@@ -616,8 +669,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
     const float s = wave_max_f32(pk_s);
     const float t = wave_max_f32(pk_t);
     if (lane == 0) {
-      ((float LGD_GLOBAL *)sg.peak_out)[ch] = s;
-      ((float LGD_GLOBAL *)sg.peak_out)[nch + ch] = t;
+      ((float LGD_GLOBAL *)sg.peak_out)[ch0 + ch] = s;
+      ((float LGD_GLOBAL *)sg.peak_out)[nch_tot + ch0 + ch] = t;
     }
   }
 #undef F
@@ -625,10 +678,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64, G ?
 
 // ------------------------------------------------------- launch wrappers ---
 // LDS bytes one workgroup needs (also used by the host-side planner); mirrors
-// LdsLayout / PLANE in the kernel
-extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp) {
+// LdsLayout / PLANE in the kernel.  generic != 0: the run-time-channel-count kernel.
+extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
   const int halo = tp == 2 ? 24 : 12;
-  if (nch <= 2) {
+  const bool planar = !generic && (nch == 1 || (nch == 2 && chunk % 2 == 0));
+  if (planar) {
     const int pad = (chunk % 2 == 0) ? 1 : 0;
     const int plane = (halo + 4 + pad + LGD_WAVE * (chunk + pad) + 4 + 8 + 1) & ~1;
     return (size_t)nch * plane * sizeof(float);
@@ -637,34 +691,41 @@ extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp) {
   return ((size_t)(LGD_WAVE * chunk + halo + 8) * nch + 4) * sizeof(float);
 }
 
-template <int C, int G, int TP>
+template <int C, int G, int TP, bool WIDE = false>
 static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, const LgdFilt *F, int nch,
                                 hipStream_t s) {
-  const size_t lds_bytes = lgd_scan_lds_bytes(C, nch, TP);
+  const size_t lds_bytes = lgd_scan_lds_bytes(C, nch, TP, G == 0);
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)lgd_scan_kernel<C, G, TP>,
+    hipError_t e = hipFuncSetAttribute((const void *)lgd_scan_kernel<C, G, TP, WIDE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((lgd_scan_kernel<C, G, TP>), dim3(n_seg), dim3(LGD_WAVE * nch), lds_bytes, s,
+  hipLaunchKernelGGL((lgd_scan_kernel<C, G, TP, WIDE>), dim3(n_seg), dim3(LGD_WAVE * nch), lds_bytes, s,
                      segs, F, nch);
   return hipGetLastError();
 }
 
-template <int C, int TP>
-static hipError_t launch_scan_g(int nch, const LgdSeg *segs, int n_seg, const LgdFilt *F,
-                                hipStream_t s) {
-  if (nch == 1) return launch_scan_t<C, 1, TP>(segs, n_seg, F, nch, s);
-  if (nch == 2) return launch_scan_t<C, 2, TP>(segs, n_seg, F, nch, s);
-  return launch_scan_t<C, 0, TP>(segs, n_seg, F, nch, s);
+// the generic kernel (any channel count, channel groups, any sub-block alignment)
+// exists for the shortest chunk only
+#define LGD_GENERIC_CHUNK 25
+template <int TP>
+static hipError_t launch_scan_generic(int nch, const LgdSeg *segs, int n_seg, const LgdFilt *F,
+                                      hipStream_t s) {
+  if (nch <= 8) return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, false>(segs, n_seg, F, nch, s);
+  return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, true>(segs, n_seg, F, nch, s);
 }
 
 template <int C>
 static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, const LgdFilt *F,
                                 hipStream_t s) {
-  if (tp == 4) return launch_scan_g<C, 4>(nch, segs, n_seg, F, s);
-  if (tp == 2) return launch_scan_g<C, 2>(nch, segs, n_seg, F, s);
-  return launch_scan_g<C, 0>(nch, segs, n_seg, F, s);
+  if (nch == 1) {
+    if (tp == 4) return launch_scan_t<C, 1, 4>(segs, n_seg, F, nch, s);
+    if (tp == 2) return launch_scan_t<C, 1, 2>(segs, n_seg, F, nch, s);
+    return launch_scan_t<C, 1, 0>(segs, n_seg, F, nch, s);
+  }
+  if (tp == 4) return launch_scan_t<C, 2, 4>(segs, n_seg, F, nch, s);
+  if (tp == 2) return launch_scan_t<C, 2, 2>(segs, n_seg, F, nch, s);
+  return launch_scan_t<C, 2, 0>(segs, n_seg, F, nch, s);
 }
 
 // chunk lengths compiled in; the host picks one that divides the rate's s100
@@ -672,10 +733,17 @@ extern "C" const int lgd_chunk_table[] = {25, 35, 40, 42, 45, 48, 49, 50, 60, 63
 
 
 // F: DEVICE pointer to the group's constants
-extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
-                                      const LgdFilt *F, hipStream_t s) {
+extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, const LgdSeg *segs,
+                                      int n_seg, const LgdFilt *F, hipStream_t s) {
   if (n_seg <= 0) return hipSuccess;
   if (nch < 1 || nch > 16) return hipErrorInvalidValue;
+  if (generic) {
+    if (chunk != LGD_GENERIC_CHUNK) return hipErrorInvalidValue;
+    if (tp == 4) return launch_scan_generic<4>(nch, segs, n_seg, F, s);
+    if (tp == 2) return launch_scan_generic<2>(nch, segs, n_seg, F, s);
+    return launch_scan_generic<0>(nch, segs, n_seg, F, s);
+  }
+  if (nch > 2) return hipErrorInvalidValue;
   switch (chunk) {
     case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, F, s);
     case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, F, s);
