@@ -436,7 +436,7 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
         g.nch = g_nch;
         g.nch_total = tr.channels;
         g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
-        g.chunk = g_nch <= 2 ? pick_chunk(c->p_chunk, s100, g_nch, g.tp) : 0;
+        g.chunk = (g_nch <= 2 && g_nch == tr.channels) ? pick_chunk(c->p_chunk, s100, g_nch, g.tp) : 0;
         // fast kernels: mono / stereo with a chunk that divides the sub-block; anything else
         // (more channels, channel groups, rates such as 11 025 Hz) goes to the generic kernel,
         // where sub-block boundaries may fall inside a chunk
