@@ -96,15 +96,22 @@ const char *lgd_last_error(void);
 
 /* tuning knobs: "chunk" (frames per lane, 0 = auto), "seg_subblocks" (100 ms
  * sub-blocks per wave segment, 0 = auto), "warm_subblocks" (K-filter warm-up
- * before a segment, default 2 = 200 ms: measured 2e-16 relative to any longer warm-up), "waves_per_cu" (auto segmentation target). */
+ * before a segment, default 2 = 200 ms: measured 2e-16 relative to any longer warm-up), "waves_per_cu" (auto segmentation target), "timing" (1 = bracket the scan kernel
+ * with hipEvents for lgd_kernel_ms_stats, default; 0 = no event packets), "overlap"
+ * (1 = consecutive lgd_execute calls alternate between the caller's stream and an
+ * internal one so that independent scans pipeline, default; 0 = strictly serial on
+ * the caller's stream, which is what kernel timings should be taken in). */
 int lgd_set_param(lgd_ctx *ctx, const char *name, long value);
 
 /* Build the segment table + workspace for a batch of tracks (host work and
  * hipMalloc happen here, never in lgd_execute). */
 int lgd_plan(lgd_ctx *ctx, const lgd_track *tracks, uint32_t n_tracks, uint32_t flags);
-/* Enqueue the whole scan on `hip_stream` (hipStream_t as void*; NULL = default
- * stream): K-weight + block-energy + peak kernel(s), gating / LRA epilogue and,
- * with LGD_FLAG_ALBUM, the album stages.  Asynchronous, no allocation. */
+/* Enqueue the whole scan (hipStream_t as void*; NULL = default stream): K-weight +
+ * block-energy + peak kernel(s), gating / LRA epilogue and, with LGD_FLAG_ALBUM, the
+ * album stages.  Asynchronous, no allocation.  Work enqueued on `hip_stream` before
+ * the call is ordered before the scan; the scan itself may run on an internal stream
+ * (see "overlap"), so its results are defined after lgd_fetch, not after a
+ * synchronisation of `hip_stream` alone. */
 int lgd_execute(lgd_ctx *ctx, void *hip_stream);
 /* Synchronise the stream used by the last lgd_execute and copy results out.
  * `album` may be NULL. */

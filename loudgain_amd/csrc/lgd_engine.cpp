@@ -197,7 +197,7 @@ static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at m
 
 struct lgd_ctx {
   int device = 0;
-  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0;
+  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 1;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -210,9 +210,8 @@ struct lgd_ctx {
   std::vector<Group> groups;
   uint64_t total_sb = 0, total_e = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0,
            warm_bytes = 0;
-  // device workspace.  Everything a scan writes exists twice (WorkSet): while
-  // the gating / LRA epilogue of scan k runs on the side stream, the dominant
-  // kernel of scan k+1 already runs on the caller's stream into the other set.
+  // device workspace.  Everything a scan writes exists twice (WorkSet): scans
+  // alternate between the two sets and between two streams (see lgd_execute).
   struct WorkSet {
     double *d_E = nullptr, *d_Z = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
     double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr;  // per-slice gating partials
@@ -223,8 +222,8 @@ struct lgd_ctx {
     LgdRange *h_album_range = nullptr;  // pinned
     size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_segs = 0,
            cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0;
-    hipEvent_t ev_scan = nullptr, ev_done = nullptr;
-    bool busy = false;  // an epilogue of this set has been enqueued on the side stream
+    hipEvent_t ev_scan = nullptr, ev_done = nullptr;  // ev_scan: caller-stream marker for the side stream
+    bool busy = false;
   } ws[2];
   int n_sets = 1;     // 2 unless the caller drives the album stages itself
   int cur_set = 0;    // set of the last lgd_execute
@@ -326,6 +325,8 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "warm_subblocks")) c->p_warm_sb = value;
   else if (!strcmp(name, "waves_per_cu")) c->p_waves_per_cu = value ? value : 8;
   else if (!strcmp(name, "debug")) c->p_debug = value;  // kernel floor measurements only
+  else if (!strcmp(name, "timing")) { c->p_timing = value; return LGD_OK; }  // hipEvent brackets on/off
+  else if (!strcmp(name, "overlap")) c->p_overlap = value;  // 0: every scan on the caller's stream
   else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
   c->planned = false;
   return LGD_OK;
@@ -497,7 +498,7 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   // the caller-driven (multi-GPU) album keeps one set: its partial pointers are
   // handed out once and the stages run on the caller's stream
   HIPCHK(hipDeviceSynchronize());  // nothing of an older plan may still be running
-  c->n_sets = (flags & LGD_FLAG_ALBUM_PART1) ? 1 : 2;
+  c->n_sets = ((flags & LGD_FLAG_ALBUM_PART1) || !c->p_overlap) ? 1 : 2;
   c->cur_set = 0;
   int rc;
   if ((rc = ensure(&c->d_slices, &c->cap_slices, c->slices.size()))) return rc;
@@ -576,46 +577,48 @@ extern "C" int lgd_album_stage3(lgd_ctx *c, const double *st_all, uint64_t n_slo
 extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   if (!c || !c->planned) return fail(LGD_ESTATE, "lgd_execute before lgd_plan");
   HIPCHK(hipSetDevice(c->device));
-  hipStream_t s = (hipStream_t)hip_stream;
+  hipStream_t caller = (hipStream_t)hip_stream;
   const int n = (int)c->tracks.size();
-  c->last_stream = s;
+  c->last_stream = caller;
   const int k = c->executed ? (c->cur_set + 1) % c->n_sets : 0;
   lgd_ctx::WorkSet &w = c->ws[k];
   c->cur_set = k;
-  // two sets: the epilogue goes to the side stream and overlaps the next scan
-  const bool overlap = c->n_sets == 2;
-  hipStream_t es = overlap ? c->side : s;
+  // Two work sets: whole scans alternate between the caller's stream and an internal one.
+  // Consecutive scans are independent (own workspace), so nothing orders them: the
+  // next scan's workgroups fill the GPU as the previous scan's drain, and its small
+  // gating / LRA kernels run beside the following scan -- no event packets between
+  // the dominant kernels.  Results are defined after lgd_fetch (which joins both).
+  hipStream_t s = caller;
+  if (c->n_sets == 2 && k == 1) {
+    s = c->side;
+    // everything the caller enqueued before this call (e.g. the PCM upload) comes first
+    HIPCHK(hipEventRecord(w.ev_scan, caller));
+    HIPCHK(hipStreamWaitEvent(s, w.ev_scan, 0));
+  }
   hipEvent_t *ev = c->ev[c->n_exec % lgd_ctx::EV_RING];
-  if (overlap && w.busy) HIPCHK(hipStreamWaitEvent(s, w.ev_done, 0));  // set k is free again
-  HIPCHK(hipEventRecord(ev[0], s));
+  if (c->p_timing) HIPCHK(hipEventRecord(ev[0], s));
   for (size_t gi = 0; gi < c->groups.size(); ++gi) {
     const Group &g = c->groups[gi];
     HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, g.generic ? 1 : 0, w.d_segs + g.seg_begin,
                            (int)g.seg_count, c->d_filt + gi, s));
   }
-  HIPCHK(hipEventRecord(ev[1], s));
-  if (overlap) {
-    HIPCHK(hipEventRecord(w.ev_scan, s));
-    HIPCHK(hipStreamWaitEvent(es, w.ev_scan, 0));
-  }
+  if (c->p_timing) HIPCHK(hipEventRecord(ev[1], s));
   HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, w.d_E, w.d_Z,
                                    w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_res, c->abs_gate,
-                                   c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, es));
-  HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, es));
+                                   c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
+  HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, s));
   c->executed = true;
   if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))
-    HIPCHK(lgd_launch_album_part1(w.d_res, n, w.d_part1, es));
+    HIPCHK(lgd_launch_album_part1(w.d_res, n, w.d_part1, s));
   if (c->flags & LGD_FLAG_ALBUM) {
     int rc;
-    if ((rc = album_stage2_on(c, w, es))) return rc;
-    if ((rc = album_stage3_on(c, w, nullptr, 0, es))) return rc;
+    if ((rc = album_stage2_on(c, w, s))) return rc;
+    if ((rc = album_stage3_on(c, w, nullptr, 0, s))) return rc;
   }
-  HIPCHK(hipEventRecord(ev[2], es));
-  if (overlap) {
-    HIPCHK(hipEventRecord(w.ev_done, es));
-    w.busy = true;
+  if (c->p_timing) {
+    HIPCHK(hipEventRecord(ev[2], s));
+    ++c->n_exec;
   }
-  ++c->n_exec;
   return LGD_OK;
 }
 

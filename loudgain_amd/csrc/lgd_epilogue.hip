@@ -219,8 +219,9 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
 // by an MSB-first radix select over the IEEE bit patterns (positive doubles
 // order like their bits), so no sort and no histogram quantisation.  Up to
 // LGD_LRA_CAP energies are staged in LDS once; longer inputs stream from L2.
-#define LGD_LRA_NT 1024
-#define LGD_LRA_CAP 7168  // doubles in LDS (56 KiB)
+#define LGD_LRA_NT 256  // one wave per SIMD at 32 VGPRs: fits next to two 197-VGPR scan waves
+#define LGD_LRA_CAP 384   // doubles staged in LDS (3 KiB): small on purpose, so that the workgroup fits
+                          // next to the scan kernel it overlaps with (which leaves ~5 KB LDS per CU)
 
 __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__restrict__ ranges,
                                                             const double *__restrict__ st_base,
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__r
   for (int pass = 0; pass < 8; ++pass) {
     const int sh_bits = 56 - 8 * pass;
     const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (sh_bits + 8));
-    if (tid < 512) hist[tid >> 8][tid & 255] = 0u;
+    for (int i = tid; i < 512; i += LGD_LRA_NT) hist[i >> 8][i & 255] = 0u;
     __syncthreads();
     const unsigned long long p0 = s_prefix[0], p1 = s_prefix[1];
     for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {

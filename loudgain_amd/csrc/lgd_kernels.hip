@@ -90,10 +90,7 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 //     PO + f + floor(f / C) * PAD,   PO = HALO + PAD + (run-time alignment shift)
 template <int C, int G>
 struct LdsLayout {
-  // (stereo with odd C keeps the interleaved layout: its 2-way ds_read conflicts are
-  // invisible next to the fp64 work, and one ds_write_b128 per vector beats the
-  // 4 v_mov + 2 ds_write_b64 of the planar scatter)
-  static constexpr bool PLANAR = (G == 1) || (G == 2 && C % 2 == 0);
+  static constexpr bool PLANAR = (G == 1) || (G == 2);
   static constexpr int PAD = (PLANAR && (C % 2 == 0)) ? 1 : 0;
   static constexpr int STRIDE = C + PAD;  // lane stride inside a plane
 };
@@ -230,9 +227,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       } else if constexpr (G == 1 && LL::PAD == 0) {                                     \
         *reinterpret_cast<f32x4 *>(lds + 4 * (idx_)) = (v_);                             \
       } else if constexpr (G == 2 && LL::PAD == 0) {                                     \
+        /* four scalar stores: hipcc pairs them into two ds_write2_b32 (data from two   */ \
+        /* separate VGPRs), so the de-interleave costs no register shuffling           */ \
         const int jj_ = 2 * (idx_);                                                      \
-        *reinterpret_cast<float2 *>(lds + jj_) = make_float2((v_).x, (v_).z);            \
-        *reinterpret_cast<float2 *>(lds + PLANE + jj_) = make_float2((v_).y, (v_).w);    \
+        lds[jj_] = (v_).x;                                                               \
+        lds[jj_ + 1] = (v_).z;                                                           \
+        lds[PLANE + jj_] = (v_).y;                                                       \
+        lds[PLANE + jj_ + 1] = (v_).w;                                                   \
       } else {                                                                           \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                               \
           const int i_ = 4 * (idx_) + e_;                                                \
@@ -681,7 +682,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 // LdsLayout / PLANE in the kernel.  generic != 0: the run-time-channel-count kernel.
 extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
   const int halo = tp == 2 ? 24 : 12;
-  const bool planar = !generic && (nch == 1 || (nch == 2 && chunk % 2 == 0));
+  const bool planar = !generic && nch <= 2;
   if (planar) {
     const int pad = (chunk % 2 == 0) ? 1 : 0;
     const int plane = (halo + 4 + pad + LGD_WAVE * (chunk + pad) + 4 + 8 + 1) & ~1;
