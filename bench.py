@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=int, default=1800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel floor measurement: 1 no loads, 2 no arithmetic")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal of the N>1 path on one GPU: RCCL group of one rank, album exchange every step")
     ap.add_argument("--serial", action="store_true",
                     help="no stream pipelining of consecutive scans (the mode rocprofv3 kernel durations are quoted in)")
     args = ap.parse_args()
@@ -76,9 +78,11 @@ def main():
         raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = world > 1 or args.force_dist
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     rate, ch = 48000, 2
     frames = int(round(args.minutes * 60 * rate))
@@ -100,13 +104,13 @@ def main():
     if args.serial:
         sc.set_param("overlap", 0)
     stream = torch.cuda.Stream(device=dev)
-    if world > 1:
-        job = DistributedAlbumScanner(sc, [pcm], rate, true_peak=true_peak)
+    if distributed:
+        job = DistributedAlbumScanner(sc, [pcm], rate, true_peak=true_peak, always_exchange=True)
     else:
         job = sc.plan([pcm], rate, true_peak=true_peak, album=False)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -119,7 +123,7 @@ def main():
     results = job.fetch()  # synchronises the stream, copies the numbers out
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -132,7 +136,7 @@ def main():
     # behind the previous launch.  The dominant kernel is therefore timed right after
     # the region, same process and buffers, with the launches strictly serial on the
     # launch stream (hipEvents recorded on that stream around every launch).
-    overlapped = world == 1 and not args.serial
+    overlapped = not args.serial
     if overlapped:
         sc.set_param("overlap", 0)
         sc.plan([pcm], rate, true_peak=true_peak, album=False)
@@ -176,7 +180,7 @@ def main():
                 "workload": "%s: %g min 48 kHz stereo f32 per GPU, K-filter + gated loudness + LRA%s%s"
                             % (args.workload.upper(), args.minutes,
                                " + 4x true peak" if true_peak else ", no true peak",
-                               "; %d-track album, RCCL album reduce per step" % world if world > 1 else ""),
+                               "; %d-track album, RCCL album reduce per step" % world if distributed else ""),
                 "frames_per_gpu": frames, "channels": ch, "rate": rate,
                 "chunk": info["chunk"], "segments": info["segments"],
                 "x_realtime": round(value * 1e6 / (rate * ch), 0),
@@ -199,7 +203,7 @@ def main():
             host = pcm[: secs * rate].cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(host, rate, secs)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -78,16 +78,18 @@ typedef struct {
   uint64_t n_abs, n_rel, n_st;
 } lgd_album_result;
 
-/* album partials exchanged between GPUs (one RCCL all-reduce each) */
+/* What ranks exchange for an album (one all-gather each, see below).
+ * Record 1 is `n_doubles` doubles: this head, then the rank's listed 3 s energies
+ * (0.0 = no entry), then 0.0 padding up to the "album_slots" parameter. */
 typedef struct {
-  double sum_abs; /* all-reduce SUM */
-  double n_abs;   /* all-reduce SUM (integer-valued, exact below 2^53) */
-  double peak;    /* all-reduce MAX */
-  double n_st;    /* all-reduce SUM */
+  double sum_abs; /* sum of the 400 ms block energies above the absolute gate */
+  double n_abs;   /* their count (integer-valued, exact below 2^53) */
+  double peak;    /* max over this rank's tracks */
+  double n_st;    /* listed short-term blocks */
 } lgd_album_part1;
 typedef struct {
-  double sum_rel; /* all-reduce SUM */
-  double n_rel;   /* all-reduce SUM */
+  double sum_rel; /* sum / count above the album's relative gate */
+  double n_rel;
 } lgd_album_part2;
 
 lgd_ctx *lgd_create(int device);
@@ -100,7 +102,8 @@ const char *lgd_last_error(void);
  * with hipEvents for lgd_kernel_ms_stats, default; 0 = no event packets), "overlap"
  * (1 = consecutive lgd_execute calls alternate between the caller's stream and an
  * internal one so that independent scans pipeline, default; 0 = strictly serial on
- * the caller's stream, which is what kernel timings should be taken in). */
+ * the caller's stream, which is what kernel timings should be taken in), "album_slots"
+ * (short-term slots in album record 1, see the multi-GPU album below; 0 = this plan's own). */
 int lgd_set_param(lgd_ctx *ctx, const char *name, long value);
 
 /* Build the segment table + workspace for a batch of tracks (host work and
@@ -117,17 +120,31 @@ int lgd_execute(lgd_ctx *ctx, void *hip_stream);
  * `album` may be NULL. */
 int lgd_fetch(lgd_ctx *ctx, lgd_track_result *tracks_out, lgd_album_result *album);
 
-/* Multi-GPU album: lgd_execute() leaves this rank's part1 in the ctx; exchange
- * it (device pointers, all-reduce in place), then run stage 2, exchange part2,
- * gather the short-term energies and finish with stage 3. */
-int lgd_album_part1_ptr(lgd_ctx *ctx, lgd_album_part1 **dev_ptr);
-int lgd_album_part2_ptr(lgd_ctx *ctx, lgd_album_part2 **dev_ptr);
-int lgd_album_stage2(lgd_ctx *ctx, void *hip_stream);
-/* this rank's listed short-term energies (unlisted slots hold 0.0) */
-int lgd_album_st_ptr(lgd_ctx *ctx, double **dev_ptr, uint64_t *n_slots);
-/* st_all: device array of n_slots energies gathered from all ranks (or NULL to
- * use this rank's own). */
-int lgd_album_stage3(lgd_ctx *ctx, const double *st_all, uint64_t n_slots, void *hip_stream);
+/* Multi-GPU album (plan with LGD_FLAG_ALBUM_PART1).  Two all-gathers per album:
+ *   lgd_execute                      this rank's record 1 (lgd_album_record1)
+ *   all-gather record 1           -> all_rec1[world][n_doubles]
+ *   lgd_album_stage2(all_rec1)       relative gate from the heads summed in rank order
+ *                                    (bit-identical on every rank), second pass over this
+ *                                    rank's blocks -> record 2; CLEARS the heads in
+ *                                    all_rec1, which thereby becomes the album's
+ *                                    short-term list and must stay valid until stage 3 ran
+ *   all-gather record 2           -> all_rec2[world]
+ *   lgd_album_stage3(all_rec2)       album loudness, range (exact order statistics over
+ *                                    the gathered list), peak -> lgd_fetch
+ * Every rank must use the same n_doubles: set "album_slots" to the largest short-term
+ * slot count of any rank (with "album_slots" 0, n_doubles - 4 is this rank's) and plan again.
+ * The getters and the stage calls refer to the workspace of the MOST RECENT lgd_execute
+ * (workspaces are used in turn, so the pointers change: query them after each
+ * lgd_execute).  The exchange may run on any stream R of the caller:
+ * lgd_album_join(ctx, R) orders R behind that scan; lgd_album_stage3 marks the end of
+ * the reduction and a later scan into the same workspace waits for it -- the exchange
+ * of scan k overlaps the kernels of scans k+1.., and lgd_fetch joins everything.
+ * all_rec1 / all_rec2 = NULL: this rank alone (what LGD_FLAG_ALBUM does internally). */
+int lgd_album_join(lgd_ctx *ctx, void *hip_stream);
+int lgd_album_record1(lgd_ctx *ctx, double **dev_ptr, uint64_t *n_doubles);
+int lgd_album_stage2(lgd_ctx *ctx, double *all_rec1, uint32_t world, void *hip_stream);
+int lgd_album_record2(lgd_ctx *ctx, double **dev_ptr); /* 2 doubles, lgd_album_part2 */
+int lgd_album_stage3(lgd_ctx *ctx, const double *all_rec2, uint32_t world, void *hip_stream);
 
 /* per-track block energies for parity tests: 100 ms sub-block energies
  * (sum_c w_c sum y^2, not yet divided by the block length) */

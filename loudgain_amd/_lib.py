@@ -39,9 +39,9 @@ FLAG_ALBUM_PART1 = 4
 # every symbol include/loudscan_device.h declares
 DEVICE_SYMBOLS = [
     "lgd_create", "lgd_destroy", "lgd_last_error", "lgd_set_param", "lgd_plan", "lgd_execute",
-    "lgd_fetch", "lgd_album_part1_ptr", "lgd_album_part2_ptr", "lgd_album_stage2",
-    "lgd_album_st_ptr", "lgd_album_stage3", "lgd_copy_subblock_energies", "lgd_last_kernel_ms",
-    "lgd_kernel_ms_stats", "lgd_plan_info",
+    "lgd_fetch", "lgd_album_record1", "lgd_album_record2", "lgd_album_stage2",
+    "lgd_album_stage3", "lgd_copy_subblock_energies", "lgd_last_kernel_ms",
+    "lgd_kernel_ms_stats", "lgd_plan_info", "lgd_album_join",
 ]
 
 
@@ -73,11 +73,11 @@ def load():
     L.lgd_plan.argtypes = [vp, C.POINTER(LgdTrack), C.c_uint32, C.c_uint32]
     L.lgd_execute.argtypes = [vp, vp]
     L.lgd_fetch.argtypes = [vp, C.POINTER(LgdTrackResult), C.POINTER(LgdAlbumResult)]
-    L.lgd_album_part1_ptr.argtypes = [vp, C.POINTER(vp)]
-    L.lgd_album_part2_ptr.argtypes = [vp, C.POINTER(vp)]
-    L.lgd_album_stage2.argtypes = [vp, vp]
-    L.lgd_album_st_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
-    L.lgd_album_stage3.argtypes = [vp, vp, C.c_uint64, vp]
+    L.lgd_album_record1.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.lgd_album_record2.argtypes = [vp, C.POINTER(vp)]
+    L.lgd_album_stage2.argtypes = [vp, vp, C.c_uint32, vp]
+    L.lgd_album_join.argtypes = [vp, vp]
+    L.lgd_album_stage3.argtypes = [vp, vp, C.c_uint32, vp]
     L.lgd_copy_subblock_energies.argtypes = [vp, C.c_uint32, vp, C.c_uint64,
                                              C.POINTER(C.c_uint64)]
     L.lgd_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]

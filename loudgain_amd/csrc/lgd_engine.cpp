@@ -36,10 +36,11 @@ extern "C" hipError_t lgd_launch_album_part1(const double *res, int n_tracks, do
                                              hipStream_t s);
 extern "C" hipError_t lgd_launch_album_stage2(const LgdSlice *slices, int n_slices,
                                               const LgdTrackMeta *meta, const double *Z,
-                                              const double *p1, double *p2a, const double *part1,
-                                              double *part2, double abs_gate, double rel_factor,
+                                              const double *p1, double *p2a, double *rec1_all,
+                                              int world, long long rec_stride, double *part1,
+                                              double *rec2, double abs_gate, double rel_factor,
                                               hipStream_t s);
-extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *part2,
+extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *rec2_all, int world,
                                              double rel_factor, double *album, hipStream_t s);
 
 static thread_local std::string g_err;
@@ -197,7 +198,8 @@ static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at m
 
 struct lgd_ctx {
   int device = 0;
-  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 1;
+  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 1,
+       p_album_slots = 0;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -209,23 +211,28 @@ struct lgd_ctx {
   std::vector<LgdSlice> slices;
   std::vector<Group> groups;
   uint64_t total_sb = 0, total_e = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0,
-           warm_bytes = 0;
+           warm_bytes = 0, rec1_len = 4;
   // device workspace.  Everything a scan writes exists twice (WorkSet): scans
   // alternate between the two sets and between two streams (see lgd_execute).
   struct WorkSet {
     double *d_E = nullptr, *d_Z = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
     double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr;  // per-slice gating partials
-    double *d_part1 = nullptr, *d_part2 = nullptr;
+    // album: record 1 = {sum_abs, n_abs, peak, n_st | st energies | 0-padding}, record 2 =
+    // {sum_rel, n_rel} are what ranks exchange; d_st points into record 1; part1 = folded heads
+    double *d_rec1 = nullptr, *d_rec2 = nullptr, *d_part1 = nullptr;
+    const double *lra_base = nullptr;  // short-term list of the album (set by stage 2)
+    uint64_t lra_n = 0;
     float *d_peaks = nullptr;
     LgdSeg *d_segs = nullptr;       // descriptors carry pointers into this set's E / peaks
     LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
     LgdRange *h_album_range = nullptr;  // pinned
     size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_segs = 0,
-           cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0;
+           cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0, cap_rec1 = 0;
     hipEvent_t ev_scan = nullptr, ev_done = nullptr;  // ev_scan: caller-stream marker for the side stream
-    bool busy = false;
-  } ws[2];
-  int n_sets = 1;     // 2 unless the caller drives the album stages itself
+    hipEvent_t ev_album = nullptr;  // end of a caller-driven album stage 3 on this set
+    bool busy = false, album_pending = false;
+  } ws[4];
+  int n_sets = 1;     // 2 pipelined; 4 when the caller drives the album stages (their exchange lags the scans)
   int cur_set = 0;    // set of the last lgd_execute
   hipStream_t side = nullptr;
   LgdSlice *d_slices = nullptr;
@@ -278,11 +285,12 @@ extern "C" lgd_ctx *lgd_create(int device) {
   for (auto &w : c->ws) {
     ok = ok && hipMalloc((void **)&w.d_album, 16 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void **)&w.d_part1, 4 * sizeof(double)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&w.d_part2, 2 * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&w.d_rec2, 2 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void **)&w.d_album_range, sizeof(LgdRange)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&w.h_album_range, sizeof(LgdRange)) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&w.ev_scan, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&w.ev_album, hipEventDisableTiming) == hipSuccess;
   }
   ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->d_filt, MAX_GROUPS * sizeof(LgdFilt)) == hipSuccess;
@@ -299,13 +307,14 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (auto &w : c->ws) {
-    void *ptrs[] = {w.d_E, w.d_Z, w.d_st, w.d_res, w.d_album, w.d_part1, w.d_part2, w.d_peaks,
+    void *ptrs[] = {w.d_E, w.d_Z, w.d_rec1, w.d_res, w.d_album, w.d_part1, w.d_rec2, w.d_peaks,
                     w.d_segs, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a};
     for (void *p : ptrs)
       if (p) (void)hipFree(p);
     if (w.h_album_range) (void)hipHostFree(w.h_album_range);
     if (w.ev_scan) (void)hipEventDestroy(w.ev_scan);
     if (w.ev_done) (void)hipEventDestroy(w.ev_done);
+    if (w.ev_album) (void)hipEventDestroy(w.ev_album);
   }
   void *ptrs2[] = {c->d_meta, c->d_slices, c->d_filt};
   for (void *p : ptrs2)
@@ -327,6 +336,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "debug")) c->p_debug = value;  // kernel floor measurements only
   else if (!strcmp(name, "timing")) { c->p_timing = value; return LGD_OK; }  // hipEvent brackets on/off
   else if (!strcmp(name, "overlap")) c->p_overlap = value;  // 0: every scan on the caller's stream
+  else if (!strcmp(name, "album_slots")) c->p_album_slots = value;  // short-term slots of album record 1
   else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
   c->planned = false;
   return LGD_OK;
@@ -495,10 +505,12 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     c->segs.insert(c->segs.end(), group_segs[gi].begin(), group_segs[gi].end());
   }
 
-  // the caller-driven (multi-GPU) album keeps one set: its partial pointers are
-  // handed out once and the stages run on the caller's stream
   HIPCHK(hipDeviceSynchronize());  // nothing of an older plan may still be running
-  c->n_sets = ((flags & LGD_FLAG_ALBUM_PART1) || !c->p_overlap) ? 1 : 2;
+  c->n_sets = c->p_overlap ? ((flags & LGD_FLAG_ALBUM_PART1) ? 4 : 2) : 1;
+  if (c->p_album_slots && (uint64_t)c->p_album_slots < c->total_st)
+    return fail(LGD_EINVAL, "album_slots %ld < the %llu short-term slots of this plan", c->p_album_slots,
+                (unsigned long long)c->total_st);
+  c->rec1_len = 4 + std::max<uint64_t>(c->total_st, (uint64_t)c->p_album_slots);
   c->cur_set = 0;
   int rc;
   if ((rc = ensure(&c->d_slices, &c->cap_slices, c->slices.size()))) return rc;
@@ -507,12 +519,16 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   for (int k = 0; k < c->n_sets; ++k) {
     lgd_ctx::WorkSet &w = c->ws[k];
     w.busy = false;
+    w.album_pending = false;
+    w.lra_base = nullptr;
     if ((rc = ensure(&w.d_E, &w.cap_E, c->total_e))) return rc;
     if ((rc = ensure(&w.d_Z, &w.cap_Z, c->total_sb))) return rc;
     if ((rc = ensure(&w.d_p1, &w.cap_p1, 4 * c->slices.size()))) return rc;
     if ((rc = ensure(&w.d_p2, &w.cap_p2, 2 * c->slices.size()))) return rc;
     if ((rc = ensure(&w.d_p2a, &w.cap_p2a, 2 * c->slices.size()))) return rc;
-    if ((rc = ensure(&w.d_st, &w.cap_st, c->total_st))) return rc;
+    if ((rc = ensure(&w.d_rec1, &w.cap_rec1, (size_t)c->rec1_len))) return rc;
+    HIPCHK(hipMemset(w.d_rec1, 0, (size_t)c->rec1_len * sizeof(double)));  // the padding stays 0
+    w.d_st = w.d_rec1 + 4;
     if ((rc = ensure(&w.d_res, &w.cap_res, (size_t)n * LGR_STRIDE))) return rc;
     if ((rc = ensure(&w.d_peaks, &w.cap_peaks, c->total_peak_floats))) return rc;
     if ((rc = ensure(&w.d_segs, &w.cap_segs, c->segs.size()))) return rc;
@@ -546,32 +562,61 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   return LGD_OK;
 }
 
-static int album_stage2_on(lgd_ctx *c, lgd_ctx::WorkSet &w, hipStream_t s) {
+// all1: records 1 of all ranks (world * rec1_len doubles, writable) or null = this rank alone
+static int album_stage2_on(lgd_ctx *c, lgd_ctx::WorkSet &w, double *all1, uint32_t world,
+                           hipStream_t s) {
+  if (!all1) {
+    all1 = w.d_rec1;
+    world = 1;
+  }
   HIPCHK(lgd_launch_album_stage2(c->d_slices, (int)c->slices.size(), c->d_meta, w.d_Z, w.d_p1,
-                                 w.d_p2a, w.d_part1, w.d_part2, c->abs_gate, c->rel_factor, s));
+                                 w.d_p2a, all1, (int)world, (long long)c->rec1_len, w.d_part1,
+                                 w.d_rec2, c->abs_gate, c->rel_factor, s));
+  w.lra_base = all1;
+  w.lra_n = (uint64_t)world * c->rec1_len;
   return LGD_OK;
 }
 
-static int album_stage3_on(lgd_ctx *c, lgd_ctx::WorkSet &w, const double *st_all, uint64_t n_slots,
+static int album_stage3_on(lgd_ctx *c, lgd_ctx::WorkSet &w, const double *all2, uint32_t world,
                            hipStream_t s) {
-  HIPCHK(lgd_launch_album_final(w.d_part1, w.d_part2, c->rel_factor, w.d_album, s));
+  if (!w.lra_base) return fail(LGD_ESTATE, "album stage 3 before stage 2");
+  if (!all2) {
+    all2 = w.d_rec2;
+    world = 1;
+  }
+  HIPCHK(lgd_launch_album_final(w.d_part1, all2, (int)world, c->rel_factor, w.d_album, s));
+  // (same values on every use of a plan, so a host that runs ahead of the copies is harmless)
   w.h_album_range->off = 0;
-  w.h_album_range->n = st_all ? (long long)n_slots : (long long)c->total_st;
+  w.h_album_range->n = (long long)w.lra_n;
   w.h_album_range->out = w.d_album + 1;
   HIPCHK(hipMemcpyAsync(w.d_album_range, w.h_album_range, sizeof(LgdRange), hipMemcpyHostToDevice, s));
-  HIPCHK(lgd_launch_lra(w.d_album_range, 1, st_all ? st_all : w.d_st, c->minus20, s));
+  HIPCHK(lgd_launch_lra(w.d_album_range, 1, w.lra_base, c->minus20, s));
   return LGD_OK;
 }
 
-extern "C" int lgd_album_stage2(lgd_ctx *c, void *hip_stream) {
+extern "C" int lgd_album_stage2(lgd_ctx *c, double *all_rec1, uint32_t world, void *hip_stream) {
   if (!c || !c->planned || !c->executed) return fail(LGD_ESTATE, "album stage 2 before execute");
-  return album_stage2_on(c, c->ws[c->cur_set], (hipStream_t)hip_stream);
+  if (all_rec1 && world == 0) return fail(LGD_EINVAL, "album stage 2: world 0");
+  return album_stage2_on(c, c->ws[c->cur_set], all_rec1, world, (hipStream_t)hip_stream);
 }
 
-extern "C" int lgd_album_stage3(lgd_ctx *c, const double *st_all, uint64_t n_slots,
+extern "C" int lgd_album_stage3(lgd_ctx *c, const double *all_rec2, uint32_t world,
                                 void *hip_stream) {
   if (!c || !c->planned || !c->executed) return fail(LGD_ESTATE, "album stage 3 before execute");
-  return album_stage3_on(c, c->ws[c->cur_set], st_all, n_slots, (hipStream_t)hip_stream);
+  if (all_rec2 && world == 0) return fail(LGD_EINVAL, "album stage 3: world 0");
+  lgd_ctx::WorkSet &w = c->ws[c->cur_set];
+  int rc = album_stage3_on(c, w, all_rec2, world, (hipStream_t)hip_stream);
+  if (rc) return rc;
+  // the next scan into this set must not start before the album of this one is done
+  HIPCHK(hipEventRecord(w.ev_album, (hipStream_t)hip_stream));
+  w.album_pending = true;
+  return LGD_OK;
+}
+
+extern "C" int lgd_album_join(lgd_ctx *c, void *hip_stream) {
+  if (!c || !c->planned || !c->executed) return fail(LGD_ESTATE, "album join before execute");
+  HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, c->ws[c->cur_set].ev_done, 0));
+  return LGD_OK;
 }
 
 extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
@@ -589,11 +634,15 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   // gating / LRA kernels run beside the following scan -- no event packets between
   // the dominant kernels.  Results are defined after lgd_fetch (which joins both).
   hipStream_t s = caller;
-  if (c->n_sets == 2 && k == 1) {
+  if (c->n_sets >= 2 && (k & 1)) {
     s = c->side;
     // everything the caller enqueued before this call (e.g. the PCM upload) comes first
     HIPCHK(hipEventRecord(w.ev_scan, caller));
     HIPCHK(hipStreamWaitEvent(s, w.ev_scan, 0));
+  }
+  if (w.album_pending) {  // a caller-driven album reduction still reads this set
+    HIPCHK(hipStreamWaitEvent(s, w.ev_album, 0));
+    w.album_pending = false;
   }
   hipEvent_t *ev = c->ev[c->n_exec % lgd_ctx::EV_RING];
   if (c->p_timing) HIPCHK(hipEventRecord(ev[0], s));
@@ -609,23 +658,26 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, s));
   c->executed = true;
   if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))
-    HIPCHK(lgd_launch_album_part1(w.d_res, n, w.d_part1, s));
+    HIPCHK(lgd_launch_album_part1(w.d_res, n, w.d_rec1, s));
   if (c->flags & LGD_FLAG_ALBUM) {
     int rc;
-    if ((rc = album_stage2_on(c, w, s))) return rc;
-    if ((rc = album_stage3_on(c, w, nullptr, 0, s))) return rc;
+    if ((rc = album_stage2_on(c, w, nullptr, 1, s))) return rc;
+    if ((rc = album_stage3_on(c, w, nullptr, 1, s))) return rc;
   }
   if (c->p_timing) {
     HIPCHK(hipEventRecord(ev[2], s));
     ++c->n_exec;
   }
+  if (c->flags & LGD_FLAG_ALBUM_PART1) HIPCHK(hipEventRecord(w.ev_done, s));  // for lgd_album_join
   return LGD_OK;
 }
 
 // both streams of the last scans
 static int sync_all(lgd_ctx *c) {
   HIPCHK(hipStreamSynchronize(c->last_stream));
-  if (c->n_sets == 2) HIPCHK(hipStreamSynchronize(c->side));
+  if (c->n_sets >= 2) HIPCHK(hipStreamSynchronize(c->side));
+  for (int k = 0; k < c->n_sets; ++k)
+    if (c->ws[k].album_pending) HIPCHK(hipEventSynchronize(c->ws[k].ev_album));
   return LGD_OK;
 }
 
@@ -675,21 +727,16 @@ extern "C" int lgd_fetch(lgd_ctx *c, lgd_track_result *out, lgd_album_result *al
   return LGD_OK;
 }
 
-extern "C" int lgd_album_part1_ptr(lgd_ctx *c, lgd_album_part1 **p) {
-  if (!c || !p) return fail(LGD_EINVAL, "null argument");
-  *p = (lgd_album_part1 *)c->ws[0].d_part1;
-  return LGD_OK;
-}
-extern "C" int lgd_album_part2_ptr(lgd_ctx *c, lgd_album_part2 **p) {
-  if (!c || !p) return fail(LGD_EINVAL, "null argument");
-  *p = (lgd_album_part2 *)c->ws[0].d_part2;
-  return LGD_OK;
-}
-extern "C" int lgd_album_st_ptr(lgd_ctx *c, double **p, uint64_t *n_slots) {
-  if (!c || !p || !n_slots) return fail(LGD_EINVAL, "null argument");
+extern "C" int lgd_album_record1(lgd_ctx *c, double **p, uint64_t *n_doubles) {
+  if (!c || !p || !n_doubles) return fail(LGD_EINVAL, "null argument");
   if (!c->planned) return fail(LGD_ESTATE, "no plan");
-  *p = c->ws[0].d_st;
-  *n_slots = c->total_st;
+  *p = c->ws[c->cur_set].d_rec1;
+  *n_doubles = c->rec1_len;
+  return LGD_OK;
+}
+extern "C" int lgd_album_record2(lgd_ctx *c, double **p) {
+  if (!c || !p) return fail(LGD_EINVAL, "null argument");
+  *p = c->ws[c->cur_set].d_rec2;
   return LGD_OK;
 }
 

@@ -14,6 +14,11 @@
 #include <math.h>
 #include <stdint.h>
 
+// The epilogue kernels are a few workgroups that run beside the next scan's
+// full grid (lgd_execute pipelines scans): give their waves issue priority so the
+// latency-bound reductions do not crawl behind 2000 streaming waves.
+#define LGD_EPI_PRIO() __builtin_amdgcn_s_setprio(3)
+
 #include "lgd_internal.h"
 
 #define LGD_WAVE 64
@@ -61,6 +66,7 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
     const LgdSlice *__restrict__ slices, const LgdTrackMeta *__restrict__ meta,
     const double *__restrict__ E_all, double *__restrict__ Z_all, double *__restrict__ st_all,
     double *__restrict__ p1, double abs_gate) {
+  LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
   const LgdSlice sl = slices[blockIdx.x];
   const LgdTrackMeta m = meta[sl.track];
@@ -118,12 +124,16 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
 }
 
 // ---- pass 2: relative gate (E7).  thr comes from this track's own pass-1 totals
-// or, for the album pass, from the (possibly all-reduced) album part1.
+// or, for the album pass, from the album records of all ranks (`world` records of
+// `rec_stride` doubles, {sum_abs, n_abs, ...} in front; summed in rank order, so every
+// workgroup and every rank gets the same bits).
 // p2[slice] = { n_rel, sum_rel }
 __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass2(
     const LgdSlice *__restrict__ slices, const LgdTrackMeta *__restrict__ meta,
     const double *__restrict__ Z_all, const double *__restrict__ p1, double *__restrict__ p2,
-    const double *__restrict__ album_part1, double abs_gate, double rel_factor) {
+    const double *__restrict__ album_rec1, int world, long long rec_stride, double abs_gate,
+    double rel_factor) {
+  LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
   const LgdSlice sl = slices[blockIdx.x];
   const LgdTrackMeta m = meta[sl.track];
@@ -131,9 +141,13 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass2(
   const int tid = threadIdx.x;
   const int j1 = min(sl.j0 + LGD_SLICE, m.n_sb - 3);
   double n_abs, sum_abs;
-  if (album_part1) {
-    sum_abs = album_part1[0];
-    n_abs = album_part1[1];
+  if (album_rec1) {
+    sum_abs = 0.0;
+    n_abs = 0.0;
+    for (int r = 0; r < world; ++r) {
+      sum_abs += album_rec1[(size_t)r * rec_stride + 0];
+      n_abs += album_rec1[(size_t)r * rec_stride + 1];
+    }
   } else {
     double a = 0.0, b = 0.0;
     for (int i = tid; i < m.n_slices; i += LGD_EPI_NT) {
@@ -166,6 +180,7 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
     const LgdTrackMeta *__restrict__ meta, const double *__restrict__ p1,
     const double *__restrict__ p2, const float *__restrict__ peaks, double *__restrict__ res_all,
     double rel_factor, int do_tp) {
+  LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
   const LgdTrackMeta m = meta[blockIdx.x];
   double *res = res_all + (size_t)blockIdx.x * LGR_STRIDE;
@@ -226,6 +241,7 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
 __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__restrict__ ranges,
                                                             const double *__restrict__ st_base,
                                                             double minus20) {
+  LGD_EPI_PRIO();
   __shared__ double sh[LGD_LRA_NT / LGD_WAVE];
   __shared__ double cache[LGD_LRA_CAP];
   __shared__ unsigned hist[2][256];
@@ -320,10 +336,12 @@ __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__r
 }
 
 // ---- album stages (scan.c:359-405) ---------------------------------------
-// part1 = { sum_abs, n_abs, peak, n_st } over this rank's tracks
+// head of this rank's album record 1 = { sum_abs, n_abs, peak, n_st } over its tracks
+// (the listed 3 s energies follow it in the same buffer)
 __global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part1_kernel(const double *__restrict__ res,
                                                                     int n_tracks,
                                                                     double *__restrict__ part1) {
+  LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
   double sa = 0.0, na = 0.0, pk = 0.0, ns = 0.0;
   for (int t = threadIdx.x; t < n_tracks; t += LGD_EPI_NT) {
@@ -342,10 +360,17 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part1_kernel(const doubl
   }
 }
 
-// part2 = { sum_rel, n_rel } over all slices of this rank (album second pass)
+// record 2 = { sum_rel, n_rel } over all slices of this rank (album second pass).
+// Thread 0 also folds the record-1 heads of all ranks into part1 = { sum_abs, n_abs,
+// peak, n_st } (rank order) and then clears them: from here on the gathered buffer is
+// nothing but the album's short-term list (0.0 = no entry) for lgd_lra_kernel.
 __global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part2_kernel(const double *__restrict__ p2a,
                                                                     int n_slices,
-                                                                    double *__restrict__ part2) {
+                                                                    double *__restrict__ rec2,
+                                                                    double *__restrict__ rec1_all,
+                                                                    int world, long long rec_stride,
+                                                                    double *__restrict__ part1) {
+  LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
   double sr = 0.0, nr = 0.0;
   for (int i = threadIdx.x; i < n_slices; i += LGD_EPI_NT) {
@@ -355,27 +380,41 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part2_kernel(const doubl
   sr = block_sum_f64<LGD_EPI_NT>(sr, sh);
   nr = block_sum_f64<LGD_EPI_NT>(nr, sh);
   if (threadIdx.x == 0) {
-    part2[0] = sr; part2[1] = nr;
+    rec2[0] = sr; rec2[1] = nr;
+    double sa = 0.0, na = 0.0, pk = 0.0, ns = 0.0;
+    for (int r = 0; r < world; ++r) {
+      double *h = rec1_all + (size_t)r * rec_stride;
+      sa += h[0]; na += h[1]; pk = fmax(pk, h[2]); ns += h[3];
+      h[0] = 0.0; h[1] = 0.0; h[2] = 0.0; h[3] = 0.0;
+    }
+    part1[0] = sa; part1[1] = na; part1[2] = pk; part1[3] = ns;
   }
 }
 
 // album[] = { loudness, lra (lgd_lra_kernel), peak, thr, sum_abs, sum_rel, n_abs, n_rel, n_st }
+// rec2_all: the records 2 of all ranks, summed in rank order
 __global__ void lgd_album_final_kernel(const double *__restrict__ part1,
-                                       const double *__restrict__ part2, double rel_factor,
-                                       double *__restrict__ album) {
+                                       const double *__restrict__ rec2_all, int world,
+                                       double rel_factor, double *__restrict__ album) {
+  LGD_EPI_PRIO();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double thr = 0.0;
   if (part1[1] > 0.0) {
     thr = part1[0] / part1[1];
     thr *= rel_factor;
   }
-  album[0] = part2[1] > 0.0 ? energy_to_loudness(part2[0] / part2[1]) : -HUGE_VAL;
+  double sr = 0.0, nr = 0.0;
+  for (int r = 0; r < world; ++r) {
+    sr += rec2_all[2 * (size_t)r + 0];
+    nr += rec2_all[2 * (size_t)r + 1];
+  }
+  album[0] = nr > 0.0 ? energy_to_loudness(sr / nr) : -HUGE_VAL;
   album[2] = part1[2];
   album[3] = thr;
   album[4] = part1[0];
-  album[5] = part2[0];
+  album[5] = sr;
   album[6] = part1[1];
-  album[7] = part2[1];
+  album[7] = nr;
   album[8] = part1[3];
 }
 
@@ -391,7 +430,7 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
     hipLaunchKernelGGL(lgd_gate_pass1, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, E, Z, st,
                        p1, abs_gate);
     hipLaunchKernelGGL(lgd_gate_pass2, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, Z, p1, p2,
-                       (const double *)nullptr, abs_gate, rel_factor);
+                       (const double *)nullptr, 0, 0LL, abs_gate, rel_factor);
   }
   hipLaunchKernelGGL(lgd_track_final, dim3(n_tracks), dim3(LGD_EPI_NT), 0, s, meta, p1, p2, peaks, res,
                      rel_factor, do_tp);
@@ -414,19 +453,22 @@ extern "C" hipError_t lgd_launch_album_part1(const double *res, int n_tracks, do
 
 extern "C" hipError_t lgd_launch_album_stage2(const LgdSlice *slices, int n_slices,
                                               const LgdTrackMeta *meta, const double *Z,
-                                              const double *p1, double *p2a, const double *part1,
-                                              double *part2, double abs_gate, double rel_factor,
+                                              const double *p1, double *p2a, double *rec1_all,
+                                              int world, long long rec_stride, double *part1,
+                                              double *rec2, double abs_gate, double rel_factor,
                                               hipStream_t s) {
   if (n_slices > 0)
     hipLaunchKernelGGL(lgd_gate_pass2, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, Z, p1, p2a,
-                       part1, abs_gate, rel_factor);
-  hipLaunchKernelGGL(lgd_album_part2_kernel, dim3(1), dim3(LGD_EPI_NT), 0, s, p2a, n_slices, part2);
+                       (const double *)rec1_all, world, rec_stride, abs_gate, rel_factor);
+  hipLaunchKernelGGL(lgd_album_part2_kernel, dim3(1), dim3(LGD_EPI_NT), 0, s, p2a, n_slices, rec2,
+                     rec1_all, world, rec_stride, part1);
   return hipGetLastError();
 }
 
-extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *part2,
+extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *rec2_all, int world,
                                              double rel_factor, double *album, hipStream_t s) {
-  hipLaunchKernelGGL(lgd_album_final_kernel, dim3(1), dim3(1), 0, s, part1, part2, rel_factor, album);
+  hipLaunchKernelGGL(lgd_album_final_kernel, dim3(1), dim3(1), 0, s, part1, rec2_all, world,
+                     rel_factor, album);
   return hipGetLastError();
 }
 

@@ -123,17 +123,21 @@ class DeviceScanner:
         return dict(segments=ns.value, subblocks=nb.value, chunk=ck.value, pcm_bytes=pb.value,
                     warm_bytes=wb.value)
 
-    # -- multi-GPU album plumbing (device pointers of the partials) -----------------
-    def album_part_ptrs(self):
-        p1, p2, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    # -- multi-GPU album plumbing (device pointers of the exchanged records) ---------
+    def album_records(self):
+        """(record 1 pointer, its length in doubles, record 2 pointer) of the most recent execute."""
+        r1, r2 = C.c_void_p(), C.c_void_p()
         n = C.c_uint64()
-        self._chk(self.L.lgd_album_part1_ptr(self.ctx, C.byref(p1)))
-        self._chk(self.L.lgd_album_part2_ptr(self.ctx, C.byref(p2)))
-        self._chk(self.L.lgd_album_st_ptr(self.ctx, C.byref(st), C.byref(n)))
-        return p1.value, p2.value, st.value, n.value
+        self._chk(self.L.lgd_album_record1(self.ctx, C.byref(r1), C.byref(n)))
+        self._chk(self.L.lgd_album_record2(self.ctx, C.byref(r2)))
+        return r1.value, n.value, r2.value
 
-    def album_stage2(self, stream=None):
-        self._chk(self.L.lgd_album_stage2(self.ctx, _stream_handle(stream)))
+    def album_join(self, stream=None):
+        """Order `stream` behind the most recent execute (which may run on an internal stream)."""
+        self._chk(self.L.lgd_album_join(self.ctx, _stream_handle(stream)))
 
-    def album_stage3(self, st_all_ptr=None, n_slots=0, stream=None):
-        self._chk(self.L.lgd_album_stage3(self.ctx, st_all_ptr, n_slots, _stream_handle(stream)))
+    def album_stage2(self, all_rec1_ptr=None, world=1, stream=None):
+        self._chk(self.L.lgd_album_stage2(self.ctx, all_rec1_ptr, world, _stream_handle(stream)))
+
+    def album_stage3(self, all_rec2_ptr=None, world=1, stream=None):
+        self._chk(self.L.lgd_album_stage3(self.ctx, all_rec2_ptr, world, _stream_handle(stream)))

@@ -12,36 +12,50 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleShard:
-    """Stands in for DeviceShard on the CPU: partials from the oracle's block lists."""
+    """Stands in for DeviceShard on the CPU: records from the oracle's block lists."""
 
-    def __init__(self, states):
+    def __init__(self, states, group=None):
         import torch
+        from loudgain_amd.album import common_slots
         self.gate = [s.gating_blocks() for s in states]
-        self.stb = [s.shortterm_blocks() for s in states]
+        stb = [s.shortterm_blocks() for s in states]
         allb = np.concatenate(self.gate) if self.gate else np.zeros(0)
+        st = np.concatenate(stb) if stb else np.zeros(0)
         peak = max([s.peak() for s in states], default=0.0)
-        n_st = sum(len(x) for x in self.stb)
-        self.part1 = torch.tensor([allb.sum(), float(len(allb)), peak, float(n_st)], dtype=torch.float64)
-        self.part2 = torch.zeros(2, dtype=torch.float64)
+        slots = common_slots(len(st), group)
+        rec1 = np.zeros(4 + slots)
+        rec1[:4] = [allb.sum(), float(len(allb)), peak, float(len(st))]
+        rec1[4:4 + len(st)] = st
+        self.rec1 = torch.from_numpy(rec1)
+        self.rec2 = torch.zeros(2, dtype=torch.float64)
+        self.index = 0
         self.result = None
 
-    def stage2(self):
-        thr = 0.0
-        if self.part1[1] > 0:
-            thr = float(self.part1[0] / self.part1[1]) * 10.0 ** (-10.0 / 10.0)
+    def stage2(self, all1, world):
+        if all1 is None:
+            all1, world = self.rec1, 1
+        heads = all1.view(world, -1)[:, :4]
+        sum_abs = n_abs = n_st = 0.0
+        peak = 0.0
+        for r in range(world):   # rank order, like lgd_album_part2_kernel
+            sum_abs += float(heads[r, 0]); n_abs += float(heads[r, 1]); n_st += float(heads[r, 3])
+            peak = max(peak, float(heads[r, 2]))
+        heads.zero_()            # what is left is the album's short-term list
+        thr = sum_abs / n_abs * 10.0 ** (-10.0 / 10.0) if n_abs > 0 else 0.0
         allb = np.concatenate(self.gate) if self.gate else np.zeros(0)
         sel = allb[allb >= thr]
-        self.part2[0], self.part2[1] = float(sel.sum()), float(len(sel))
+        self.rec2[0], self.rec2[1] = float(sel.sum()), float(len(sel))
+        self.peak, self.st_all = peak, all1
 
-    def st_energies(self):
-        import torch
-        v = np.concatenate(self.stb) if self.stb else np.zeros(0)
-        return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64))
-
-    def finish(self, st_all):
+    def finish(self, all2, world):
         from loudgain_amd.album import album_from_partials
-        self.result = album_from_partials(float(self.part2[0]), float(self.part2[1]), st_all.numpy(),
-                                          float(self.part1[2]))
+        if all2 is None:
+            all2, world = self.rec2, 1
+        p = all2.view(world, 2)
+        sum_rel = n_rel = 0.0
+        for r in range(world):
+            sum_rel += float(p[r, 0]); n_rel += float(p[r, 1])
+        self.result = album_from_partials(sum_rel, n_rel, self.st_all.numpy(), self.peak)
 
 
 def _tracks():

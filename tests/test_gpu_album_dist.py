@@ -23,7 +23,7 @@ def _tracks():
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -31,26 +31,35 @@ def _worker(rank, world, port, q):
     from loudgain_amd.device import DeviceScanner
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     tracks = _tracks()
     mine = shard_indices(len(tracks), rank, world)
     dev = [torch.from_numpy(tracks[i][0]).cuda() for i in mine]
-    job = DistributedAlbumScanner(DeviceScanner(0), dev, [tracks[i][1] for i in mine])
+    job = DistributedAlbumScanner(DeviceScanner(0), dev, [tracks[i][1] for i in mine],
+                                  always_exchange=(backend == "nccl"))
     stream = torch.cuda.Stream()
-    for _ in range(2):  # executing twice must give the same answer (partials are rebuilt each time)
+    # five pipelined scans (both workspaces, scan k+1 under the exchange of scan k): the
+    # last one must still be right, partials are rebuilt every time
+    for _ in range(5):
         job.execute(stream)
     tr, album = job.fetch()
     q.put((rank, mine, tr, album))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_album_matches_oracle(oracle, world):
+@pytest.mark.parametrize("world,backend", [(1, "gloo"), (2, "gloo"), (3, "gloo"), (1, "nccl")])
+def test_sharded_album_matches_oracle(oracle, world, backend):
+    """(1, "nccl"): the RCCL calls themselves (all-reduce SUM/MAX on engine-owned HBM,
+    all-gather into a tensor) with one rank, where every collective is an identity."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29700 + (os.getpid() % 2000) + world + (7 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
