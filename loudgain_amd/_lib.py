@@ -2,7 +2,10 @@
 import ctypes as C
 import os
 
-from .build import LIB
+from .build import LIB as _DEFAULT_LIB
+
+# measurement builds only (e.g. csrc/libloudscan_hip_dbg.so with the kernel floor modes)
+LIB = os.environ.get("LOUDSCAN_LIB", _DEFAULT_LIB)
 
 _L = None
 

@@ -65,6 +65,14 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   v += dpp_f64<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
   return __shfl(v, LGD_WAVE - 1, LGD_WAVE);
 }
+
+// lane l <- lane l-1, lane 0 <- fill: DPP wave_shr:1 (a VALU move, no LDS round trip;
+// lanes without a source keep `old`)
+__device__ __forceinline__ double lgd_wave_shr1(double v, double fill) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, LGD_WAVE));
@@ -331,6 +339,28 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           qv[h_][3] = qv[h_][2]; qv[h_][2] = qv[h_][1]; qv[h_][1] = qv[h_][0]; qv[h_][0] = q0_; \
           pv[h_][3] = pv[h_][2]; pv[h_][2] = pv[h_][1]; pv[h_][1] = pv[h_][0]; pv[h_][0] = p0_; \
         } while (0)
+        // both streams at once, statement by statement: neighbouring instructions are
+        // independent, so a wave issues back to back instead of waiting ~2 issue slots
+        // for each link of one stream's dependency chain
+#define LGD_A_STEP2(u_)                                                                 \
+        do {                                                                            \
+          double ta_ = fma(-ra2, qv[0][1], (double)xa[0][u_]);                          \
+          double tb_ = fma(-ra2, qv[1][1], (double)xa[1][u_]);                          \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+          const double qa_ = fma(-ra1, qv[0][0], ta_);                                  \
+          const double qb_ = fma(-ra1, qv[1][0], tb_);                                  \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+          ta_ = fma(-pa2, pv[0][1], qa_);                                               \
+          tb_ = fma(-pa2, pv[1][1], qb_);                                               \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+          const double pa_ = fma(-pa1, pv[0][0], ta_);                                  \
+          const double pb_ = fma(-pa1, pv[1][0], tb_);                                  \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+          qv[0][3] = qv[0][2]; qv[0][2] = qv[0][1]; qv[0][1] = qv[0][0]; qv[0][0] = qa_; \
+          qv[1][3] = qv[1][2]; qv[1][2] = qv[1][1]; qv[1][1] = qv[1][0]; qv[1][0] = qb_; \
+          pv[0][3] = pv[0][2]; pv[0][2] = pv[0][1]; pv[0][1] = pv[0][0]; pv[0][0] = pa_; \
+          pv[1][3] = pv[1][2]; pv[1][2] = pv[1][1]; pv[1][1] = pv[1][0]; pv[1][0] = pb_; \
+        } while (0)
         const int a_end2 = (dbg & 4) ? 0 : H2, a_end1 = (dbg & 4) ? 0 : H1;
 #pragma unroll 2
         for (int j0 = 0; j0 < a_end2; j0 += U) {  // both streams (x2: the register copies of the read pipeline fold away)
@@ -341,10 +371,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
             xn[1][u] = LGD_X(H1 + j0 + U + u);
           }
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            LGD_A_STEP(0, u);
-            LGD_A_STEP(1, u);
-          }
+          for (int u = 0; u < U; ++u) LGD_A_STEP2(u);
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             xa[0][u] = xn[0][u];
@@ -362,6 +389,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           for (int u = 0; u < U; ++u) xa[0][u] = xn[u];
         }
 #undef LGD_A_STEP
+#undef LGD_A_STEP2
         // zero-state end states in the scan basis; the runs assumed a zero input
         // history: the true x[-1], x[-2] in front of a sub-chunk change its w[0] by
         // -2x[-1] + x[-2] and its w[1] by x[-1] (g = their effect on the end state)
@@ -387,10 +415,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           const auto *P = Fk->MH2;
 #pragma unroll
           for (int r = 0; r < 4; ++r) z1[r] = zz[0][r];
-          z[0] = zz[1][0] + fma(P[1], z1[1], P[0] * z1[0]);
-          z[1] = zz[1][1] + fma(P[5], z1[1], P[4] * z1[0]);
-          z[2] = zz[1][2] + fma(P[11], z1[3], fma(P[10], z1[2], fma(P[9], z1[1], P[8] * z1[0])));
-          z[3] = zz[1][3] + fma(P[15], z1[3], fma(P[14], z1[2], fma(P[13], z1[1], P[12] * z1[0])));
+          z[0] = fma(P[1], z1[1], fma(P[0], z1[0], zz[1][0]));
+          z[1] = fma(P[5], z1[1], fma(P[4], z1[0], zz[1][1]));
+          z[2] = fma(P[11], z1[3], fma(P[10], z1[2], fma(P[9], z1[1], fma(P[8], z1[0], zz[1][2]))));
+          z[3] = fma(P[15], z1[3], fma(P[14], z1[2], fma(P[13], z1[1], fma(P[12], z1[0], zz[1][3]))));
         }
       }
 
@@ -398,10 +426,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       // transition is block lower triangular: rows 0,1 see columns 0,1 only. ----
       if (lane == 0) {
         const auto *P = Fk->P[0];
-        z[0] += fma(P[1], cin[1], P[0] * cin[0]);
-        z[1] += fma(P[5], cin[1], P[4] * cin[0]);
-        z[2] += fma(P[11], cin[3], fma(P[10], cin[2], fma(P[9], cin[1], P[8] * cin[0])));
-        z[3] += fma(P[15], cin[3], fma(P[14], cin[2], fma(P[13], cin[1], P[12] * cin[0])));
+        z[0] = fma(P[1], cin[1], fma(P[0], cin[0], z[0]));
+        z[1] = fma(P[5], cin[1], fma(P[4], cin[0], z[1]));
+        z[2] = fma(P[11], cin[3], fma(P[10], cin[2], fma(P[9], cin[1], fma(P[8], cin[0], z[2]))));
+        z[3] = fma(P[15], cin[3], fma(P[14], cin[2], fma(P[13], cin[1], fma(P[12], cin[0], z[3]))));
       }
 #pragma unroll
       for (int s = 0; s < 6; ++s) {
@@ -413,24 +441,31 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         // is zero to double precision: those steps move and multiply half as much
         const bool shelf = !((pskip >> s) & 1);  // wave-uniform
         double u[4];
-        u[0] = __shfl_up(z[0], d, LGD_WAVE);
-        u[1] = __shfl_up(z[1], d, LGD_WAVE);
-        if (shelf) {
-          u[2] = __shfl_up(z[2], d, LGD_WAVE);
-          u[3] = __shfl_up(z[3], d, LGD_WAVE);
+        if (s == 0) {  // distance 1: DPP
+          u[0] = lgd_wave_shr1(z[0], 0.0);
+          u[1] = lgd_wave_shr1(z[1], 0.0);
+          u[2] = shelf ? lgd_wave_shr1(z[2], 0.0) : 0.0;
+          u[3] = shelf ? lgd_wave_shr1(z[3], 0.0) : 0.0;
         } else {
-          u[2] = u[3] = 0.0;
+          u[0] = __shfl_up(z[0], d, LGD_WAVE);
+          u[1] = __shfl_up(z[1], d, LGD_WAVE);
+          if (shelf) {
+            u[2] = __shfl_up(z[2], d, LGD_WAVE);
+            u[3] = __shfl_up(z[3], d, LGD_WAVE);
+          } else {
+            u[2] = u[3] = 0.0;
+          }
         }
         if (lane >= d) {  // exec-masked, no cross-lane traffic inside
-          z[0] += fma(P[1], u[1], P[0] * u[0]);
-          z[1] += fma(P[5], u[1], P[4] * u[0]);
-          double t2 = fma(P[9], u[1], P[8] * u[0]), t3 = fma(P[13], u[1], P[12] * u[0]);
+          z[0] = fma(P[1], u[1], fma(P[0], u[0], z[0]));
+          z[1] = fma(P[5], u[1], fma(P[4], u[0], z[1]));
+          double t2 = fma(P[9], u[1], fma(P[8], u[0], z[2])), t3 = fma(P[13], u[1], fma(P[12], u[0], z[3]));
           if (shelf) {
             t2 = fma(P[11], u[3], fma(P[10], u[2], t2));
             t3 = fma(P[15], u[3], fma(P[14], u[2], t3));
           }
-          z[2] += t2;
-          z[3] += t3;
+          z[2] = t2;
+          z[3] = t3;
         }
       }
       // z is now the exact state at the END of each lane's chunk; the state at
@@ -439,16 +474,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       double sv[2][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double up = __shfl_up(z[r], 1, LGD_WAVE);
-        sv[0][r] = (lane == 0) ? cin[r] : up;
+        sv[0][r] = lgd_wave_shr1(z[r], cin[r]);
         cin[r] = __shfl(z[r], LGD_WAVE - 1, LGD_WAVE);
       }
       {
         const auto *P = Fk->MH1;
-        sv[1][0] = z1[0] + fma(P[1], sv[0][1], P[0] * sv[0][0]);
-        sv[1][1] = z1[1] + fma(P[5], sv[0][1], P[4] * sv[0][0]);
-        sv[1][2] = z1[2] + fma(P[11], sv[0][3], fma(P[10], sv[0][2], fma(P[9], sv[0][1], P[8] * sv[0][0])));
-        sv[1][3] = z1[3] + fma(P[15], sv[0][3], fma(P[14], sv[0][2], fma(P[13], sv[0][1], P[12] * sv[0][0])));
+        sv[1][0] = fma(P[1], sv[0][1], fma(P[0], sv[0][0], z1[0]));
+        sv[1][1] = fma(P[5], sv[0][1], fma(P[4], sv[0][0], z1[1]));
+        sv[1][2] = fma(P[11], sv[0][3], fma(P[10], sv[0][2], fma(P[9], sv[0][1], fma(P[8], sv[0][0], z1[2]))));
+        sv[1][3] = fma(P[15], sv[0][3], fma(P[14], sv[0][2], fma(P[13], sv[0][1], fma(P[12], sv[0][0], z1[3]))));
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -562,6 +596,55 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         qs[h_][1] = qs[h_][0]; qs[h_][0] = q0_;                                         \
         ps[h_][1] = ps[h_][0]; ps[h_][0] = p0_;                                         \
       } while (0)
+      // both streams, statement by statement (see LGD_A_STEP2)
+#define LGD_C_STEP2(u_, ja_, jb_)                                                       \
+      do {                                                                              \
+        const double xa_ = (double)w[0][HX + (u_)];                                     \
+        const double xb_ = (double)w[1][HX + (u_)];                                     \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        double ta_ = fma(-2.0, xh[0][0], xa_);                                          \
+        double tb_ = fma(-2.0, xh[1][0], xb_);                                          \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        ta_ += xh[0][1];                                                                \
+        tb_ += xh[1][1];                                                                \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        xh[0][1] = xh[0][0]; xh[0][0] = xa_;                                            \
+        xh[1][1] = xh[1][0]; xh[1][0] = xb_;                                            \
+        ta_ = fma(-ra2, qs[0][1], ta_);                                                 \
+        tb_ = fma(-ra2, qs[1][1], tb_);                                                 \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        const double qa_ = fma(-ra1, qs[0][0], ta_);                                    \
+        const double qb_ = fma(-ra1, qs[1][0], tb_);                                    \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        ta_ = fma(-pa2, ps[0][1], qa_);                                                 \
+        tb_ = fma(-pa2, ps[1][1], qb_);                                                 \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        const double pa_ = fma(-pa1, ps[0][0], ta_);                                    \
+        const double pb_ = fma(-pa1, ps[1][0], tb_);                                    \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        double ya_ = fma(c1, ps[0][0], pa_);                                            \
+        double yb_ = fma(c1, ps[1][0], pb_);                                            \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        ya_ = fma(c2, ps[0][1], ya_);                                                   \
+        yb_ = fma(c2, ps[1][1], yb_);                                                   \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        if constexpr (G == 0) {                                                         \
+          const double y2a_ = ya_ * ya_, y2b_ = yb_ * yb_;                              \
+          const bool loa_ = (ja_) < bnd, lob_ = (jb_) < bnd;                            \
+          eh[0] += loa_ ? y2a_ : 0.0;                                                   \
+          eh[1] += lob_ ? y2b_ : 0.0;                                                   \
+          en[0] += loa_ ? 0.0 : y2a_;                                                   \
+          en[1] += lob_ ? 0.0 : y2b_;                                                   \
+        } else {                                                                        \
+          eh[0] = fma(ya_, ya_, eh[0]);                                                 \
+          eh[1] = fma(yb_, yb_, eh[1]);                                                 \
+          __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                               \
+        qs[0][1] = qs[0][0]; qs[0][0] = qa_;                                            \
+        qs[1][1] = qs[1][0]; qs[1][0] = qb_;                                            \
+        ps[0][1] = ps[0][0]; ps[0][0] = pa_;                                            \
+        ps[1][1] = ps[1][0]; ps[1][0] = pb_;                                            \
+      } while (0)
       const int c_end2 = (dbg & 16) ? 0 : H2, c_end1 = (dbg & 16) ? 0 : H1;
 #pragma unroll 2
       for (int j0 = 0; j0 < c_end2; j0 += U) {  // both streams
@@ -580,10 +663,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          LGD_C_STEP(0, u, j0 + u);
-          LGD_C_STEP(1, u, H1 + j0 + u);
-        }
+        for (int u = 0; u < U; ++u) LGD_C_STEP2(u, j0 + u, H1 + j0 + u);
         LGD_PEAKS_BLOCK(w[0], j0);
         LGD_PEAKS_BLOCK(w[1], H1 + j0);
         if constexpr (PIPE) {
@@ -613,6 +693,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         }
       }
 #undef LGD_C_STEP
+#undef LGD_C_STEP2
       e = eh[0] + eh[1];
       e_next = en[0] + en[1];
     } else {
