@@ -150,6 +150,11 @@ int lgd_album_stage3(lgd_ctx *ctx, const double *all_rec2, uint32_t world, void 
  * (sum_c w_c sum y^2, not yet divided by the block length) */
 int lgd_copy_subblock_energies(lgd_ctx *ctx, uint32_t track, double *host_out, uint64_t cap,
                                uint64_t *n_out);
+/* per-channel peaks of one track (ebur128_sample_peak / the interpolated peak of
+ * ebur128_true_peak, scan.c:303,371 take them channel by channel); true_peak is 0
+ * when the plan had no LGD_FLAG_TRUE_PEAK; either output may be NULL */
+int lgd_copy_channel_peaks(lgd_ctx *ctx, uint32_t track, double *sample_peak, double *true_peak,
+                           uint32_t cap_channels);
 /* kernel-only timing of the last lgd_execute on its stream (hipEvents recorded
  * on that stream around the dominant kernel and around the whole enqueue) */
 int lgd_last_kernel_ms(lgd_ctx *ctx, float *scan_ms, float *total_ms);

@@ -44,7 +44,7 @@ DEVICE_SYMBOLS = [
     "lgd_create", "lgd_destroy", "lgd_last_error", "lgd_set_param", "lgd_plan", "lgd_execute",
     "lgd_fetch", "lgd_album_record1", "lgd_album_record2", "lgd_album_stage2",
     "lgd_album_stage3", "lgd_copy_subblock_energies", "lgd_last_kernel_ms",
-    "lgd_kernel_ms_stats", "lgd_plan_info", "lgd_album_join",
+    "lgd_kernel_ms_stats", "lgd_plan_info", "lgd_album_join", "lgd_copy_channel_peaks",
 ]
 
 
@@ -80,6 +80,7 @@ def load():
     L.lgd_album_record2.argtypes = [vp, C.POINTER(vp)]
     L.lgd_album_stage2.argtypes = [vp, vp, C.c_uint32, vp]
     L.lgd_album_join.argtypes = [vp, vp]
+    L.lgd_copy_channel_peaks.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32]
     L.lgd_album_stage3.argtypes = [vp, vp, C.c_uint32, vp]
     L.lgd_copy_subblock_energies.argtypes = [vp, C.c_uint32, vp, C.c_uint64,
                                              C.POINTER(C.c_uint64)]

@@ -766,6 +766,33 @@ extern "C" int lgd_copy_subblock_energies(lgd_ctx *c, uint32_t track, double *ho
   return LGD_OK;
 }
 
+extern "C" int lgd_copy_channel_peaks(lgd_ctx *c, uint32_t track, double *sample_peak,
+                                      double *true_peak, uint32_t cap) {
+  if (!c || !c->executed) return fail(LGD_ESTATE, "lgd_copy_channel_peaks before lgd_execute");
+  if (track >= c->tracks.size()) return fail(LGD_EINVAL, "track index out of range");
+  const LgdTrackMeta &m = c->meta[track];
+  if (cap < (uint32_t)m.nch) return fail(LGD_EINVAL, "need room for %d channels", m.nch);
+  HIPCHK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = sync_all(c))) return rc;
+  std::vector<float> pk((size_t)m.n_seg * 2 * m.nch);
+  if (!pk.empty())
+    HIPCHK(hipMemcpy(pk.data(), c->ws[c->cur_set].d_peaks + m.peak_off, pk.size() * sizeof(float),
+                     hipMemcpyDeviceToHost));
+  const bool tp = (c->flags & LGD_FLAG_TRUE_PEAK) != 0;
+  for (int ch = 0; ch < m.nch; ++ch) {
+    double sp = 0.0, t = 0.0;
+    for (int sg = 0; sg < m.n_seg; ++sg) {
+      const float *pp = &pk[(size_t)sg * 2 * m.nch];
+      sp = std::max(sp, (double)pp[ch]);
+      t = std::max(t, (double)pp[m.nch + ch]);
+    }
+    if (sample_peak) sample_peak[ch] = sp;
+    if (true_peak) true_peak[ch] = tp ? t : 0.0;
+  }
+  return LGD_OK;
+}
+
 extern "C" int lgd_last_kernel_ms(lgd_ctx *c, float *scan_ms, float *total_ms) {
   if (!c || !c->n_exec) return fail(LGD_ESTATE, "no executed plan");
   hipEvent_t *ev = c->ev[(c->n_exec - 1) % lgd_ctx::EV_RING];

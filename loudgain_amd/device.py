@@ -103,6 +103,12 @@ class DeviceScanner:
                                                         C.byref(n)))
         return out
 
+    def channel_peaks(self, track, channels):
+        sp = np.zeros(channels, np.float64)
+        tp = np.zeros(channels, np.float64)
+        self._chk(self.L.lgd_copy_channel_peaks(self.ctx, track, sp.ctypes.data, tp.ctypes.data, channels))
+        return sp, tp
+
     def last_kernel_ms(self):
         a, b = C.c_float(-1), C.c_float(-1)
         self._chk(self.L.lgd_last_kernel_ms(self.ctx, C.byref(a), C.byref(b)))

@@ -1,5 +1,6 @@
 """CPU: the C-ABI shared library loads and exports every symbol that
-include/loudscan.h and include/loudscan_device.h declare (no compute calls)."""
+include/loudscan.h, include/loudscan_device.h and include/loudscan_ebur128.h declare
+(no compute calls)."""
 import ctypes
 import os
 import re
@@ -10,19 +11,41 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:scan|lgd)_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:scan|lgd|ebur128|loudscan_ebur128)_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
-    from loudgain_amd import _lib, scan
+    from loudgain_amd import _lib, ebur128, scan
     L = _lib.load()
     dev = _declared("loudscan_device.h")
     api = _declared("loudscan.h")
-    assert len(dev) >= 15 and len(api) >= 14
-    for name in dev + api:
+    shim = _declared("loudscan_ebur128.h")
+    assert len(dev) >= 15 and len(api) >= 14 and len(shim) >= 12
+    for name in dev + api + shim:
         assert hasattr(L, name), "missing export: " + name
     assert sorted(_lib.DEVICE_SYMBOLS) == dev
     assert sorted(scan.SCAN_SYMBOLS) == api
+    assert sorted(ebur128.EBUR128_SYMBOLS) == shim
+
+
+def test_ebur128_state_layout_and_version():
+    # libebur128's public struct: int mode; unsigned channels; unsigned long samplerate; d* (LP64: 24 bytes);
+    # loudgain.c:179-184 insists on >= 1.2.4
+    from loudgain_amd import ebur128
+    assert ctypes.sizeof(ebur128.Ebur128State) == 24
+    assert ebur128.Ebur128State.channels.offset == 4 and ebur128.Ebur128State.samplerate.offset == 8
+    assert ebur128.get_version() >= (1, 2, 4)
+    assert ebur128.MODE_ALL == 0b111111 and ebur128.MODE_TRUE_PEAK == 0x31 and ebur128.MODE_LRA == 0xB
+
+
+def test_ebur128_init_fails_without_gpu():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from loudgain_amd import ebur128
+    with pytest.raises(ebur128.Ebur128Error):
+        ebur128.State(2, 48000)
 
 
 def test_scan_result_layout_matches_reference_header():
