@@ -109,6 +109,13 @@ int lgd_set_param(lgd_ctx *ctx, const char *name, long value);
 /* Build the segment table + workspace for a batch of tracks (host work and
  * hipMalloc happen here, never in lgd_execute). */
 int lgd_plan(lgd_ctx *ctx, const lgd_track *tracks, uint32_t n_tracks, uint32_t flags);
+/* The same for a batch of several albums on one GPU (LGD_FLAG_ALBUM): track t belongs to
+ * album album_of_track[t] (< n_albums, non-decreasing: the tracks of an album are
+ * consecutive; an album may be empty).  One launch scans every track and reduces every
+ * album -- the shape of a library scan (one loudgain call per folder in the reference's
+ * bin/rgbpm2:120-175).  lgd_fetch then fills n_albums album records. */
+int lgd_plan_albums(lgd_ctx *ctx, const lgd_track *tracks, uint32_t n_tracks,
+                    const uint32_t *album_of_track, uint32_t n_albums, uint32_t flags);
 /* Enqueue the whole scan (hipStream_t as void*; NULL = default stream): K-weight +
  * block-energy + peak kernel(s), gating / LRA epilogue and, with LGD_FLAG_ALBUM, the
  * album stages.  Asynchronous, no allocation.  Work enqueued on `hip_stream` before
@@ -116,8 +123,8 @@ int lgd_plan(lgd_ctx *ctx, const lgd_track *tracks, uint32_t n_tracks, uint32_t 
  * (see "overlap"), so its results are defined after lgd_fetch, not after a
  * synchronisation of `hip_stream` alone. */
 int lgd_execute(lgd_ctx *ctx, void *hip_stream);
-/* Synchronise the stream used by the last lgd_execute and copy results out.
- * `album` may be NULL. */
+/* Synchronise the streams used by the last lgd_execute calls and copy results out.
+ * `album` may be NULL; otherwise it has room for one record per album of the plan. */
 int lgd_fetch(lgd_ctx *ctx, lgd_track_result *tracks_out, lgd_album_result *album);
 
 /* Multi-GPU album (plan with LGD_FLAG_ALBUM_PART1).  Two all-gathers per album:

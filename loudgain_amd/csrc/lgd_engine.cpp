@@ -32,16 +32,18 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
                                                 int do_tp, hipStream_t s);
 extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
                                      double minus20, hipStream_t s);
-extern "C" hipError_t lgd_launch_album_part1(const double *res, int n_tracks, double *part1,
-                                             hipStream_t s);
+extern "C" hipError_t lgd_launch_album_part1(const double *res, const LgdAlbumMeta *albums,
+                                             int n_albums, double *heads, hipStream_t s);
 extern "C" hipError_t lgd_launch_album_stage2(const LgdSlice *slices, int n_slices,
                                               const LgdTrackMeta *meta, const double *Z,
-                                              const double *p1, double *p2a, double *rec1_all,
-                                              int world, long long rec_stride, double *part1,
-                                              double *rec2, double abs_gate, double rel_factor,
-                                              hipStream_t s);
+                                              const double *p1, double *p2a,
+                                              const LgdAlbumMeta *albums, int n_albums,
+                                              double *heads_all, int world, long long rec_stride,
+                                              double *part1, double *rec2, double abs_gate,
+                                              double rel_factor, hipStream_t s);
 extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *rec2_all, int world,
-                                             double rel_factor, double *album, hipStream_t s);
+                                             int n_albums, double rel_factor, double *album,
+                                             hipStream_t s);
 
 static thread_local std::string g_err;
 
@@ -209,6 +211,7 @@ struct lgd_ctx {
   std::vector<LgdSeg> segs;
   std::vector<LgdRange> ranges;
   std::vector<LgdSlice> slices;
+  std::vector<LgdAlbumMeta> albums;
   std::vector<Group> groups;
   uint64_t total_sb = 0, total_e = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0,
            warm_bytes = 0, rec1_len = 4;
@@ -219,7 +222,9 @@ struct lgd_ctx {
     double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr;  // per-slice gating partials
     // album: record 1 = {sum_abs, n_abs, peak, n_st | st energies | 0-padding}, record 2 =
     // {sum_rel, n_rel} are what ranks exchange; d_st points into record 1; part1 = folded heads
-    double *d_rec1 = nullptr, *d_rec2 = nullptr, *d_part1 = nullptr;
+    // (single-GPU plans may hold many albums: heads / part1 / rec2 / album are per album)
+    double *d_rec1 = nullptr, *d_rec2 = nullptr, *d_part1 = nullptr, *d_heads = nullptr;
+    LgdRange *d_album_ranges = nullptr;  // per album, into this set's d_st (single-GPU form)
     const double *lra_base = nullptr;  // short-term list of the album (set by stage 2)
     uint64_t lra_n = 0;
     float *d_peaks = nullptr;
@@ -227,7 +232,8 @@ struct lgd_ctx {
     LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
     LgdRange *h_album_range = nullptr;  // pinned
     size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_segs = 0,
-           cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0, cap_rec1 = 0;
+           cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0, cap_rec1 = 0, cap_album = 0,
+           cap_part1 = 0, cap_rec2 = 0, cap_heads = 0, cap_album_ranges = 0;
     hipEvent_t ev_scan = nullptr, ev_done = nullptr;  // ev_scan: caller-stream marker for the side stream
     hipEvent_t ev_album = nullptr;  // end of a caller-driven album stage 3 on this set
     bool busy = false, album_pending = false;
@@ -238,7 +244,8 @@ struct lgd_ctx {
   LgdSlice *d_slices = nullptr;
   LgdFilt *d_filt = nullptr;  // [MAX_GROUPS] per-group kernel constants
   LgdTrackMeta *d_meta = nullptr;
-  size_t cap_meta = 0, cap_slices = 0;
+  LgdAlbumMeta *d_albums = nullptr;
+  size_t cap_meta = 0, cap_slices = 0, cap_albums = 0;
   hipStream_t last_stream = nullptr;
   // ring of (start, scan kernel done, all done) event triples, one per execute
   static const int EV_RING = 64;
@@ -283,9 +290,6 @@ extern "C" lgd_ctx *lgd_create(int device) {
   for (int i = 0; i < lgd_ctx::EV_RING; ++i)
     for (int j = 0; j < 3; ++j) ok = ok && hipEventCreate(&c->ev[i][j]) == hipSuccess;
   for (auto &w : c->ws) {
-    ok = ok && hipMalloc((void **)&w.d_album, 16 * sizeof(double)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&w.d_part1, 4 * sizeof(double)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&w.d_rec2, 2 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void **)&w.d_album_range, sizeof(LgdRange)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&w.h_album_range, sizeof(LgdRange)) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&w.ev_scan, hipEventDisableTiming) == hipSuccess;
@@ -308,7 +312,8 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
   (void)hipDeviceSynchronize();
   for (auto &w : c->ws) {
     void *ptrs[] = {w.d_E, w.d_Z, w.d_rec1, w.d_res, w.d_album, w.d_part1, w.d_rec2, w.d_peaks,
-                    w.d_segs, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a};
+                    w.d_segs, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a, w.d_heads,
+                    w.d_album_ranges};
     for (void *p : ptrs)
       if (p) (void)hipFree(p);
     if (w.h_album_range) (void)hipHostFree(w.h_album_range);
@@ -316,7 +321,7 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
     if (w.ev_done) (void)hipEventDestroy(w.ev_done);
     if (w.ev_album) (void)hipEventDestroy(w.ev_album);
   }
-  void *ptrs2[] = {c->d_meta, c->d_slices, c->d_filt};
+  void *ptrs2[] = {c->d_meta, c->d_slices, c->d_filt, c->d_albums};
   for (void *p : ptrs2)
     if (p) (void)hipFree(p);
   if (c->side) (void)hipStreamDestroy(c->side);
@@ -364,14 +369,30 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   return 0;
 }
 
+extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
+                               const uint32_t *album_of_track, uint32_t n_albums, uint32_t flags);
+
 extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_t flags) {
+  return lgd_plan_albums(c, tracks, n, nullptr, 1, flags);
+}
+
+extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
+                               const uint32_t *album_of_track, uint32_t n_albums, uint32_t flags) {
   if (!c) return fail(LGD_EINVAL, "lgd_plan: null context");
   if (n && !tracks) return fail(LGD_EINVAL, "lgd_plan: null track array");
+  if (n_albums == 0) return fail(LGD_EINVAL, "lgd_plan: zero albums");
+  if (n_albums > 1 && !(flags & LGD_FLAG_ALBUM))
+    return fail(LGD_EINVAL, "lgd_plan: several albums need LGD_FLAG_ALBUM (one GPU per plan)");
+  if (n_albums > 1 && !album_of_track) return fail(LGD_EINVAL, "lgd_plan: null album index array");
+  for (uint32_t t = 0; t < n && album_of_track; ++t)
+    if (album_of_track[t] >= n_albums || (t && album_of_track[t] < album_of_track[t - 1]))
+      return fail(LGD_EINVAL, "lgd_plan: album indices must be < n_albums and non-decreasing (track %u)", t);
   HIPCHK(hipSetDevice(c->device));
   c->planned = c->executed = false;
   c->flags = flags;
   c->tracks.assign(tracks, tracks + n);
   c->meta.assign(n, LgdTrackMeta());
+  c->albums.assign(n_albums, LgdAlbumMeta{0, 0, 0, 0});
   c->segs.clear();
   c->ranges.clear();
   c->slices.clear();
@@ -391,6 +412,7 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     LgdTrackMeta &m = c->meta[t];
     m.s100 = (int)((tr.rate + 5) / 10);
     m.nch = (int)tr.channels;
+    m.album = album_of_track ? (int)album_of_track[t] : 0;
     const uint64_t nsb = tr.frames / (uint64_t)m.s100;
     if (nsb > 0x7fffffffull) return fail(LGD_EUNSUP, "track %u too long", t);
     m.n_sb = (int)nsb;
@@ -405,6 +427,17 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     c->total_e += nsb * tr.channels;
     c->total_st += (uint64_t)m.n_st_slots;
     c->pcm_bytes += tr.frames * tr.channels * 4ull;
+  }
+  {  // albums = runs of consecutive tracks; an album without tracks is an empty run
+    uint32_t t = 0;
+    for (uint32_t a = 0; a < n_albums; ++a) {
+      LgdAlbumMeta &am = c->albums[a];
+      am.t0 = (int)t;
+      am.slice0 = t < n ? c->meta[t].slice_off : (int)c->slices.size();
+      while (t < n && c->meta[t].album == (int)a) ++t;
+      am.t1 = (int)t;
+      am.slice1 = t < n ? c->meta[t].slice_off : (int)c->slices.size();
+    }
   }
 
   // launch groups: tracks (or 16-channel groups of wide tracks) that share
@@ -515,6 +548,9 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   int rc;
   if ((rc = ensure(&c->d_slices, &c->cap_slices, c->slices.size()))) return rc;
   if ((rc = ensure(&c->d_meta, &c->cap_meta, n))) return rc;
+  if ((rc = ensure(&c->d_albums, &c->cap_albums, n_albums))) return rc;
+  HIPCHK(hipMemcpy(c->d_albums, c->albums.data(), n_albums * sizeof(LgdAlbumMeta), hipMemcpyHostToDevice));
+  std::vector<LgdRange> aranges(n_albums);
   c->ranges.resize(n);
   for (int k = 0; k < c->n_sets; ++k) {
     lgd_ctx::WorkSet &w = c->ws[k];
@@ -529,6 +565,21 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
     if ((rc = ensure(&w.d_rec1, &w.cap_rec1, (size_t)c->rec1_len))) return rc;
     HIPCHK(hipMemset(w.d_rec1, 0, (size_t)c->rec1_len * sizeof(double)));  // the padding stays 0
     w.d_st = w.d_rec1 + 4;
+    if ((rc = ensure(&w.d_album, &w.cap_album, (size_t)n_albums * LGD_ALBUM_STRIDE))) return rc;
+    if ((rc = ensure(&w.d_part1, &w.cap_part1, (size_t)n_albums * 4))) return rc;
+    if ((rc = ensure(&w.d_rec2, &w.cap_rec2, (size_t)n_albums * 2))) return rc;
+    if ((rc = ensure(&w.d_heads, &w.cap_heads, (size_t)n_albums * 4))) return rc;
+    if ((rc = ensure(&w.d_album_ranges, &w.cap_album_ranges, n_albums))) return rc;
+    HIPCHK(hipMemset(w.d_album, 0, (size_t)n_albums * LGD_ALBUM_STRIDE * sizeof(double)));
+    for (uint32_t a = 0; a < n_albums; ++a) {
+      const LgdAlbumMeta &am = c->albums[a];
+      long long slots = 0;
+      for (int t = am.t0; t < am.t1; ++t) slots += c->meta[t].n_st_slots;
+      aranges[a].off = am.t0 < am.t1 ? c->meta[am.t0].st_off : 0;
+      aranges[a].n = slots;
+      aranges[a].out = w.d_album + (size_t)a * LGD_ALBUM_STRIDE + 1;
+    }
+    HIPCHK(hipMemcpy(w.d_album_ranges, aranges.data(), n_albums * sizeof(LgdRange), hipMemcpyHostToDevice));
     if ((rc = ensure(&w.d_res, &w.cap_res, (size_t)n * LGR_STRIDE))) return rc;
     if ((rc = ensure(&w.d_peaks, &w.cap_peaks, c->total_peak_floats))) return rc;
     if ((rc = ensure(&w.d_segs, &w.cap_segs, c->segs.size()))) return rc;
@@ -562,17 +613,21 @@ extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_
   return LGD_OK;
 }
 
-// all1: records 1 of all ranks (world * rec1_len doubles, writable) or null = this rank alone
+// Album stages.  Multi-GPU form (LGD_FLAG_ALBUM_PART1, one album): all1 = records 1 of all
+// ranks (world * rec1_len doubles, writable; null = this rank alone), whose heads hold
+// the partial sums and whose remainder becomes the short-term list.  Single-GPU form
+// (LGD_FLAG_ALBUM, any number of albums): heads in their own array, the short-term
+// lists are the albums' slices of this set's d_st.
 static int album_stage2_on(lgd_ctx *c, lgd_ctx::WorkSet &w, double *all1, uint32_t world,
                            hipStream_t s) {
-  if (!all1) {
-    all1 = w.d_rec1;
-    world = 1;
-  }
+  const bool dist = (c->flags & LGD_FLAG_ALBUM_PART1) != 0;
+  double *heads = dist ? (all1 ? all1 : w.d_rec1) : w.d_heads;
+  if (!dist || !all1) world = 1;
   HIPCHK(lgd_launch_album_stage2(c->d_slices, (int)c->slices.size(), c->d_meta, w.d_Z, w.d_p1,
-                                 w.d_p2a, all1, (int)world, (long long)c->rec1_len, w.d_part1,
-                                 w.d_rec2, c->abs_gate, c->rel_factor, s));
-  w.lra_base = all1;
+                                 w.d_p2a, c->d_albums, (int)c->albums.size(), heads, (int)world,
+                                 (long long)c->rec1_len, w.d_part1, w.d_rec2, c->abs_gate,
+                                 c->rel_factor, s));
+  w.lra_base = dist ? heads : w.d_st;
   w.lra_n = (uint64_t)world * c->rec1_len;
   return LGD_OK;
 }
@@ -580,17 +635,23 @@ static int album_stage2_on(lgd_ctx *c, lgd_ctx::WorkSet &w, double *all1, uint32
 static int album_stage3_on(lgd_ctx *c, lgd_ctx::WorkSet &w, const double *all2, uint32_t world,
                            hipStream_t s) {
   if (!w.lra_base) return fail(LGD_ESTATE, "album stage 3 before stage 2");
-  if (!all2) {
+  const bool dist = (c->flags & LGD_FLAG_ALBUM_PART1) != 0;
+  if (!dist || !all2) {
     all2 = w.d_rec2;
     world = 1;
   }
-  HIPCHK(lgd_launch_album_final(w.d_part1, all2, (int)world, c->rel_factor, w.d_album, s));
-  // (same values on every use of a plan, so a host that runs ahead of the copies is harmless)
-  w.h_album_range->off = 0;
-  w.h_album_range->n = (long long)w.lra_n;
-  w.h_album_range->out = w.d_album + 1;
-  HIPCHK(hipMemcpyAsync(w.d_album_range, w.h_album_range, sizeof(LgdRange), hipMemcpyHostToDevice, s));
-  HIPCHK(lgd_launch_lra(w.d_album_range, 1, w.lra_base, c->minus20, s));
+  const int n_albums = (int)c->albums.size();
+  HIPCHK(lgd_launch_album_final(w.d_part1, all2, (int)world, n_albums, c->rel_factor, w.d_album, s));
+  if (dist) {
+    // (same values on every use of a plan, so a host that runs ahead of the copies is harmless)
+    w.h_album_range->off = 0;
+    w.h_album_range->n = (long long)w.lra_n;
+    w.h_album_range->out = w.d_album + 1;
+    HIPCHK(hipMemcpyAsync(w.d_album_range, w.h_album_range, sizeof(LgdRange), hipMemcpyHostToDevice, s));
+    HIPCHK(lgd_launch_lra(w.d_album_range, 1, w.lra_base, c->minus20, s));
+  } else {
+    HIPCHK(lgd_launch_lra(w.d_album_ranges, n_albums, w.d_st, c->minus20, s));
+  }
   return LGD_OK;
 }
 
@@ -658,7 +719,8 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, s));
   c->executed = true;
   if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))
-    HIPCHK(lgd_launch_album_part1(w.d_res, n, w.d_rec1, s));
+    HIPCHK(lgd_launch_album_part1(w.d_res, c->d_albums, (int)c->albums.size(),
+                                  (c->flags & LGD_FLAG_ALBUM_PART1) ? w.d_rec1 : w.d_heads, s));
   if (c->flags & LGD_FLAG_ALBUM) {
     int rc;
     if ((rc = album_stage2_on(c, w, nullptr, 1, s))) return rc;
@@ -712,17 +774,22 @@ extern "C" int lgd_fetch(lgd_ctx *c, lgd_track_result *out, lgd_album_result *al
   if (album) {
     if (!(c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1)))
       return fail(LGD_ESTATE, "plan was made without an album flag");
-    double a[9];
-    HIPCHK(hipMemcpy(a, w.d_album, sizeof(a), hipMemcpyDeviceToHost));
-    album->loudness = a[0];
-    album->lra = a[1];
-    album->peak = a[2];
-    album->rel_threshold = a[3];
-    album->sum_abs = a[4];
-    album->sum_rel = a[5];
-    album->n_abs = (uint64_t)a[6];
-    album->n_rel = (uint64_t)a[7];
-    album->n_st = (uint64_t)a[8];
+    const size_t na = c->albums.size();
+    std::vector<double> ab(na * LGD_ALBUM_STRIDE);
+    HIPCHK(hipMemcpy(ab.data(), w.d_album, ab.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < na; ++i) {
+      const double *a = &ab[i * LGD_ALBUM_STRIDE];
+      lgd_album_result &o = album[i];
+      o.loudness = a[0];
+      o.lra = a[1];
+      o.peak = a[2];
+      o.rel_threshold = a[3];
+      o.sum_abs = a[4];
+      o.sum_rel = a[5];
+      o.n_abs = (uint64_t)a[6];
+      o.n_rel = (uint64_t)a[7];
+      o.n_st = (uint64_t)a[8];
+    }
   }
   return LGD_OK;
 }

@@ -144,9 +144,10 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass2(
   if (album_rec1) {
     sum_abs = 0.0;
     n_abs = 0.0;
+    const double *head = album_rec1 + 4 * (size_t)m.album;  // (several albums only with world == 1)
     for (int r = 0; r < world; ++r) {
-      sum_abs += album_rec1[(size_t)r * rec_stride + 0];
-      n_abs += album_rec1[(size_t)r * rec_stride + 1];
+      sum_abs += head[(size_t)r * rec_stride + 0];
+      n_abs += head[(size_t)r * rec_stride + 1];
     }
   } else {
     double a = 0.0, b = 0.0;
@@ -335,16 +336,17 @@ __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__r
   }
 }
 
-// ---- album stages (scan.c:359-405) ---------------------------------------
-// head of this rank's album record 1 = { sum_abs, n_abs, peak, n_st } over its tracks
-// (the listed 3 s energies follow it in the same buffer)
+// ---- album stages (scan.c:359-405).  One workgroup per album of the plan. --------
+// head of an album record 1 = { sum_abs, n_abs, peak, n_st } over the album's tracks
+// on this rank (in the multi-GPU form the listed 3 s energies follow it in the same buffer)
 __global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part1_kernel(const double *__restrict__ res,
-                                                                    int n_tracks,
-                                                                    double *__restrict__ part1) {
+                                                                    const LgdAlbumMeta *__restrict__ albums,
+                                                                    double *__restrict__ heads) {
   LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
+  const LgdAlbumMeta am = albums[blockIdx.x];
   double sa = 0.0, na = 0.0, pk = 0.0, ns = 0.0;
-  for (int t = threadIdx.x; t < n_tracks; t += LGD_EPI_NT) {
+  for (int t = am.t0 + threadIdx.x; t < am.t1; t += LGD_EPI_NT) {
     const double *r = res + (size_t)t * LGR_STRIDE;
     sa += r[LGR_SUM_ABS];
     na += r[LGR_NABS];
@@ -356,48 +358,56 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part1_kernel(const doubl
   ns = block_sum_f64<LGD_EPI_NT>(ns, sh);
   pk = block_max_f64<LGD_EPI_NT>(pk, sh);
   if (threadIdx.x == 0) {
-    part1[0] = sa; part1[1] = na; part1[2] = pk; part1[3] = ns;
+    double *h = heads + 4 * (size_t)blockIdx.x;
+    h[0] = sa; h[1] = na; h[2] = pk; h[3] = ns;
   }
 }
 
-// record 2 = { sum_rel, n_rel } over all slices of this rank (album second pass).
-// Thread 0 also folds the record-1 heads of all ranks into part1 = { sum_abs, n_abs,
-// peak, n_st } (rank order) and then clears them: from here on the gathered buffer is
-// nothing but the album's short-term list (0.0 = no entry) for lgd_lra_kernel.
+// record 2 = { sum_rel, n_rel } over the album's slices on this rank (album second
+// pass).  Thread 0 also folds the record-1 heads of all ranks into part1 = { sum_abs,
+// n_abs, peak, n_st } (rank order) and then clears them: in the multi-GPU form the
+// gathered buffer is from here on nothing but the album's short-term list (0.0 = no
+// entry) for lgd_lra_kernel.
 __global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part2_kernel(const double *__restrict__ p2a,
-                                                                    int n_slices,
+                                                                    const LgdAlbumMeta *__restrict__ albums,
                                                                     double *__restrict__ rec2,
-                                                                    double *__restrict__ rec1_all,
+                                                                    double *__restrict__ heads_all,
                                                                     int world, long long rec_stride,
                                                                     double *__restrict__ part1) {
   LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
+  const LgdAlbumMeta am = albums[blockIdx.x];
   double sr = 0.0, nr = 0.0;
-  for (int i = threadIdx.x; i < n_slices; i += LGD_EPI_NT) {
+  for (int i = am.slice0 + threadIdx.x; i < am.slice1; i += LGD_EPI_NT) {
     nr += p2a[2 * (size_t)i + 0];
     sr += p2a[2 * (size_t)i + 1];
   }
   sr = block_sum_f64<LGD_EPI_NT>(sr, sh);
   nr = block_sum_f64<LGD_EPI_NT>(nr, sh);
   if (threadIdx.x == 0) {
-    rec2[0] = sr; rec2[1] = nr;
+    rec2[2 * (size_t)blockIdx.x + 0] = sr;
+    rec2[2 * (size_t)blockIdx.x + 1] = nr;
     double sa = 0.0, na = 0.0, pk = 0.0, ns = 0.0;
     for (int r = 0; r < world; ++r) {
-      double *h = rec1_all + (size_t)r * rec_stride;
+      double *h = heads_all + (size_t)r * rec_stride + 4 * (size_t)blockIdx.x;
       sa += h[0]; na += h[1]; pk = fmax(pk, h[2]); ns += h[3];
       h[0] = 0.0; h[1] = 0.0; h[2] = 0.0; h[3] = 0.0;
     }
-    part1[0] = sa; part1[1] = na; part1[2] = pk; part1[3] = ns;
+    double *o = part1 + 4 * (size_t)blockIdx.x;
+    o[0] = sa; o[1] = na; o[2] = pk; o[3] = ns;
   }
 }
 
-// album[] = { loudness, lra (lgd_lra_kernel), peak, thr, sum_abs, sum_rel, n_abs, n_rel, n_st }
-// rec2_all: the records 2 of all ranks, summed in rank order
-__global__ void lgd_album_final_kernel(const double *__restrict__ part1,
-                                       const double *__restrict__ rec2_all, int world,
-                                       double rel_factor, double *__restrict__ album) {
+// album[a][] = { loudness, lra (lgd_lra_kernel), peak, thr, sum_abs, sum_rel, n_abs, n_rel, n_st }
+// rec2_all: the records 2 of all ranks ([rank][album][2]), summed in rank order
+__global__ void lgd_album_final_kernel(const double *__restrict__ part1_all,
+                                       const double *__restrict__ rec2_all, int world, int n_albums,
+                                       double rel_factor, double *__restrict__ album_all) {
   LGD_EPI_PRIO();
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_albums) return;
+  const double *part1 = part1_all + 4 * (size_t)a;
+  double *album = album_all + (size_t)a * LGD_ALBUM_STRIDE;
   double thr = 0.0;
   if (part1[1] > 0.0) {
     thr = part1[0] / part1[1];
@@ -405,8 +415,8 @@ __global__ void lgd_album_final_kernel(const double *__restrict__ part1,
   }
   double sr = 0.0, nr = 0.0;
   for (int r = 0; r < world; ++r) {
-    sr += rec2_all[2 * (size_t)r + 0];
-    nr += rec2_all[2 * (size_t)r + 1];
+    sr += rec2_all[2 * ((size_t)r * n_albums + a) + 0];
+    nr += rec2_all[2 * ((size_t)r * n_albums + a) + 1];
   }
   album[0] = nr > 0.0 ? energy_to_loudness(sr / nr) : -HUGE_VAL;
   album[2] = part1[2];
@@ -445,30 +455,35 @@ extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const dou
   return hipGetLastError();
 }
 
-extern "C" hipError_t lgd_launch_album_part1(const double *res, int n_tracks, double *part1,
-                                             hipStream_t s) {
-  hipLaunchKernelGGL(lgd_album_part1_kernel, dim3(1), dim3(LGD_EPI_NT), 0, s, res, n_tracks, part1);
+extern "C" hipError_t lgd_launch_album_part1(const double *res, const LgdAlbumMeta *albums,
+                                             int n_albums, double *heads, hipStream_t s) {
+  if (n_albums <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lgd_album_part1_kernel, dim3(n_albums), dim3(LGD_EPI_NT), 0, s, res, albums, heads);
   return hipGetLastError();
 }
 
 extern "C" hipError_t lgd_launch_album_stage2(const LgdSlice *slices, int n_slices,
                                               const LgdTrackMeta *meta, const double *Z,
-                                              const double *p1, double *p2a, double *rec1_all,
-                                              int world, long long rec_stride, double *part1,
-                                              double *rec2, double abs_gate, double rel_factor,
-                                              hipStream_t s) {
+                                              const double *p1, double *p2a,
+                                              const LgdAlbumMeta *albums, int n_albums,
+                                              double *heads_all, int world, long long rec_stride,
+                                              double *part1, double *rec2, double abs_gate,
+                                              double rel_factor, hipStream_t s) {
+  if (n_albums <= 0) return hipSuccess;
   if (n_slices > 0)
     hipLaunchKernelGGL(lgd_gate_pass2, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, Z, p1, p2a,
-                       (const double *)rec1_all, world, rec_stride, abs_gate, rel_factor);
-  hipLaunchKernelGGL(lgd_album_part2_kernel, dim3(1), dim3(LGD_EPI_NT), 0, s, p2a, n_slices, rec2,
-                     rec1_all, world, rec_stride, part1);
+                       (const double *)heads_all, world, rec_stride, abs_gate, rel_factor);
+  hipLaunchKernelGGL(lgd_album_part2_kernel, dim3(n_albums), dim3(LGD_EPI_NT), 0, s, p2a, albums, rec2,
+                     heads_all, world, rec_stride, part1);
   return hipGetLastError();
 }
 
 extern "C" hipError_t lgd_launch_album_final(const double *part1, const double *rec2_all, int world,
-                                             double rel_factor, double *album, hipStream_t s) {
-  hipLaunchKernelGGL(lgd_album_final_kernel, dim3(1), dim3(1), 0, s, part1, rec2_all, world,
-                     rel_factor, album);
+                                             int n_albums, double rel_factor, double *album,
+                                             hipStream_t s) {
+  if (n_albums <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lgd_album_final_kernel, dim3((n_albums + 63) / 64), dim3(64), 0, s, part1, rec2_all,
+                     world, n_albums, rel_factor, album);
   return hipGetLastError();
 }
 

@@ -79,7 +79,13 @@ struct LgdTrackMeta {
   int nch;
   int slice_off;      // first epilogue slice of this track
   int n_slices;       // ceil((n_sb - 3) / LGD_SLICE), 0 if n_sb < 4
-  int pad;
+  int album;          // album of this track (albums are runs of consecutive tracks)
+};
+
+// one album of a plan: tracks [t0, t1), their epilogue slices [slice0, slice1)
+struct LgdAlbumMeta {
+  int t0, t1;
+  int slice0, slice1;
 };
 
 // one loudness-range problem: listed short-term energies st[off, off+n) -> *out
@@ -103,6 +109,8 @@ static inline LGD_HD double lgd_channel_weight(int ch, int nch) {
   if (ch == 4 || ch == 5) return 1.41;
   return 0.0;
 }
+
+#define LGD_ALBUM_STRIDE 16  // doubles per album result record (9 used)
 
 // per-track device result: 16 doubles (counts are integer-valued doubles)
 enum {

@@ -35,6 +35,7 @@ class DeviceScanner:
         self.device = int(device)
         self._keep = None
         self.n_tracks = 0
+        self.n_albums = None
         self.flags = 0
 
     def close(self):
@@ -52,9 +53,11 @@ class DeviceScanner:
     def set_param(self, name, value):
         self._chk(self.L.lgd_set_param(self.ctx, name.encode(), int(value)))
 
-    def plan(self, tracks, rates, true_peak=True, album=False):
+    def plan(self, tracks, rates, true_peak=True, album=False, albums=None):
         """tracks: device torch tensors [frames, channels] float32 contiguous, or
-        (ptr, frames, channels) tuples; rates: int or list of ints."""
+        (ptr, frames, channels) tuples; rates: int or list of ints.
+        albums: optional album index per track (non-decreasing): one launch scans all
+        tracks and reduces every album; fetch() then returns a list of album results."""
         if isinstance(rates, int):
             rates = [rates] * len(tracks)
         arr = (LgdTrack * max(1, len(tracks)))()
@@ -73,9 +76,17 @@ class DeviceScanner:
         self.n_tracks = len(tracks)
         # album: False | True (all stages on this GPU) | "part1" (multi-GPU: the
         # caller exchanges the partials and drives stages 2 and 3)
-        aflag = FLAG_ALBUM_PART1 if album == "part1" else (FLAG_ALBUM if album else 0)
+        aflag = FLAG_ALBUM_PART1 if album == "part1" else (FLAG_ALBUM if (album or albums is not None) else 0)
         self.flags = (FLAG_TRUE_PEAK if true_peak else 0) | aflag
-        self._chk(self.L.lgd_plan(self.ctx, arr, len(tracks), self.flags))
+        if albums is None:
+            self.n_albums = None
+            self._chk(self.L.lgd_plan(self.ctx, arr, len(tracks), self.flags))
+        else:
+            if len(albums) != len(tracks):
+                raise LoudscanError("albums: one index per track")
+            self.n_albums = (max(albums) + 1) if len(albums) else 1
+            idx = (C.c_uint32 * max(1, len(albums)))(*[int(a) for a in albums])
+            self._chk(self.L.lgd_plan_albums(self.ctx, arr, len(tracks), idx, self.n_albums, self.flags))
         return self
 
     def execute(self, stream=None):
@@ -84,14 +95,17 @@ class DeviceScanner:
 
     def fetch(self):
         res = (LgdTrackResult * max(1, self.n_tracks))()
-        alb = LgdAlbumResult()
+        na = self.n_albums or 1
+        alb = (LgdAlbumResult * na)()
         want_album = bool(self.flags & (FLAG_ALBUM | FLAG_ALBUM_PART1))
-        self._chk(self.L.lgd_fetch(self.ctx, res, C.byref(alb) if want_album else None))
+        self._chk(self.L.lgd_fetch(self.ctx, res, alb if want_album else None))
         tracks = [res[i].asdict() for i in range(self.n_tracks)]
-        return tracks, (alb.asdict() if want_album else None)
+        if not want_album:
+            return tracks, None
+        return tracks, (alb[0].asdict() if self.n_albums is None else [alb[i].asdict() for i in range(na)])
 
-    def scan(self, tracks, rates, true_peak=True, album=False, stream=None):
-        return self.plan(tracks, rates, true_peak, album).execute(stream).fetch()
+    def scan(self, tracks, rates, true_peak=True, album=False, stream=None, albums=None):
+        return self.plan(tracks, rates, true_peak, album, albums).execute(stream).fetch()
 
     # -- introspection -----------------------------------------------------------
     def subblock_energies(self, track):

@@ -227,3 +227,41 @@ def test_ten_minutes_vs_oracle(scanner, oracle):
     ref = oracle.scan_track(pcm, 48000)
     (got,), _ = scanner.scan([to_dev(pcm)], 48000)
     check_track(got, ref)
+
+
+def test_many_albums_in_one_plan(scanner, oracle):
+    """lgd_plan_albums: one launch, several albums (the library-scan shape of bin/rgbpm2):
+    every album equals the oracle's _multiple result over exactly its tracks; albums may be
+    empty, hold one short track, or mix rates and channel counts."""
+    from loudgain_amd import synth
+    specs = [  # (album, rate, ch, seconds, seed, gain)
+        (0, 48000, 2, 8.0, 1, 1.0), (0, 48000, 2, 6.5, 2, 0.03), (0, 44100, 2, 9.0, 3, 0.6),
+        (1, 48000, 1, 5.0, 4, 1.0),
+        # album 2 is empty
+        (3, 96000, 2, 4.0, 5, 0.9), (3, 48000, 6, 5.5, 6, 0.2), (3, 48000, 2, 0.25, 7, 1.0),
+        (4, 22050, 2, 7.0, 8, 0.5), (4, 48000, 2, 12.0, 9, 1.0),
+    ]
+    pcms = [synth.snap_s16_numpy(synth.track_numpy(int(r * s), c, r, seed=sd, step_s=1.5) * g)
+            for _, r, c, s, sd, g in specs]
+    albums = [a for a, *_ in specs]
+    tracks, res = scanner.scan([to_dev(p) for p in pcms], [sp[1] for sp in specs], albums=albums)
+    assert len(res) == 5
+    refs = [oracle.scan_track(p, sp[1]) for p, sp in zip(pcms, specs)]
+    for got, ref, sp in zip(tracks, refs, specs):
+        check_track(got, ref, rate=sp[1])
+    for a in range(5):
+        mine = [r for r, sp in zip(refs, specs) if sp[0] == a]
+        if not mine:
+            assert res[a]["loudness"] == -np.inf and res[a]["lra"] == 0.0 and res[a]["n_abs"] == 0
+            continue
+        states = [r["state"] for r in mine]
+        det = oracle.gating_detail(states)
+        assert res[a]["n_abs"] == det["n_abs"] and res[a]["n_rel"] == det["n_rel"]
+        assert abs(res[a]["loudness"] - oracle.album_loudness(states)) <= 1e-6
+        assert abs(res[a]["lra"] - oracle.album_lra(states)) <= 1e-6
+        assert abs(res[a]["peak"] - max(r["peak"] for r in mine)) <= 1e-4
+        assert res[a]["n_st"] == sum(r["n_st"] for r in mine)
+    # bad album arrays are refused
+    from loudgain_amd.device import LoudscanError
+    with pytest.raises(LoudscanError):
+        scanner.plan([to_dev(pcms[0]), to_dev(pcms[1])], 48000, albums=[1, 0])
