@@ -79,6 +79,20 @@ int scan_pcm_f32(const float *interleaved, size_t frames, unsigned channels, uns
                  unsigned index);
 int scan_pcm_f32_device(const float *device_interleaved, size_t frames, unsigned channels,
                         unsigned rate, unsigned index);
+/* The RIFF/WAVE reader of scan_file on its own, for callers that batch their own uploads
+ * (loudgain_amd/batch.py): probe = header only; read = the data chunk as interleaved S16
+ * exactly as scan_file stages it (8/16/24/32-bit PCM, 32/64-bit float, EXTENSIBLE).
+ * Unlike scan_file these do not exit: 0 / frames read, or -1 cannot open, -2 not
+ * RIFF/WAVE, -3 unknown sample format, -4 no audio data. */
+typedef struct {
+  int codec_id;      /* FFmpeg AVCodecID value of the PCM format */
+  unsigned channels;
+  unsigned rate;
+  unsigned bits;
+  size_t frames;     /* announced by the data chunk */
+} scan_wav_info;
+int scan_wav_probe(const char *file, scan_wav_info *out);
+long long scan_wav_read_s16(const char *file, short *out, size_t cap_frames);
 /* mark a track's codec (FFmpeg AVCodecID) for callers that decode themselves,
  * e.g. 0x1503C (Opus) to get scan.c's -5 dB pre-gain rule */
 int scan_set_codec(unsigned index, int codec_id, const char *container);

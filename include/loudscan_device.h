@@ -153,6 +153,10 @@ int lgd_album_stage2(lgd_ctx *ctx, double *all_rec1, uint32_t world, void *hip_s
 int lgd_album_record2(lgd_ctx *ctx, double **dev_ptr); /* 2 doubles, lgd_album_part2 */
 int lgd_album_stage3(lgd_ctx *ctx, const double *all_rec2, uint32_t world, void *hip_stream);
 
+/* ingest helper: interleaved S16 in HBM -> f32 / 32768 (exact; the scaling of
+ * ebur128_add_frames_short), so that PCM crosses PCIe at 2 bytes per sample */
+int lgd_convert_s16(const short *dev_in, float *dev_out, uint64_t n_samples, void *hip_stream);
+
 /* per-track block energies for parity tests: 100 ms sub-block energies
  * (sum_c w_c sum y^2, not yet divided by the block length) */
 int lgd_copy_subblock_energies(lgd_ctx *ctx, uint32_t track, double *host_out, uint64_t cap,

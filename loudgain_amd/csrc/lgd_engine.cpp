@@ -833,6 +833,13 @@ extern "C" int lgd_copy_subblock_energies(lgd_ctx *c, uint32_t track, double *ho
   return LGD_OK;
 }
 
+extern "C" hipError_t lgd_launch_s16_to_f32(const short *in, float *out, size_t n, hipStream_t s);
+extern "C" int lgd_convert_s16(const short *dev_in, float *dev_out, uint64_t n, void *hip_stream) {
+  if (n && (!dev_in || !dev_out)) return fail(LGD_EINVAL, "lgd_convert_s16: null pointer");
+  if (n) HIPCHK(lgd_launch_s16_to_f32(dev_in, dev_out, (size_t)n, (hipStream_t)hip_stream));
+  return LGD_OK;
+}
+
 extern "C" int lgd_copy_channel_peaks(lgd_ctx *c, uint32_t track, double *sample_peak,
                                       double *true_peak, uint32_t cap) {
   if (!c || !c->executed) return fail(LGD_ESTATE, "lgd_copy_channel_peaks before lgd_execute");

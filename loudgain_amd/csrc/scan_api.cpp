@@ -17,6 +17,7 @@
 #include <unistd.h>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -225,18 +226,30 @@ extern "C" int scan_set_codec(unsigned index, int codec_id, const char *containe
   return 0;
 }
 
-extern "C" int scan_file(const char *file, unsigned index) {
-  if ((int)index >= g_nb) {
-    errmsg("Index too high");
-    return -1;
-  }
+namespace {
+
+struct WavInfo {
+  int codec = 0;
+  unsigned channels = 0, rate = 0, bits = 0, block_align = 0;
+  long data_off = 0;
+  size_t frames = 0;  // as the data chunk announces; a truncated file yields fewer
+};
+
+enum { WAV_OK = 0, WAV_EOPEN = -1, WAV_ENOTWAVE = -2, WAV_ECODEC = -3, WAV_ENOAUDIO = -4 };
+
+// RIFF/WAVE header walk (stands in for avformat_open_input / find_stream_info /
+// av_find_best_stream, scan.c:139-165, for the one container readable without FFmpeg)
+int wav_probe(const char *file, WavInfo *wi) {
   FILE *fp = fopen(file, "rb");
-  if (!fp) fail("Could not open input: %s", file);
+  if (!fp) return WAV_EOPEN;
   unsigned char hdr[12], ck[8], fmt[40];
-  if (fread(hdr, 1, 12, fp) != 12 || memcmp(hdr, "RIFF", 4) || memcmp(hdr + 8, "WAVE", 4))
-    fail("Could not find stream info: %s (only RIFF/WAVE is read without FFmpeg)", file);
-  unsigned tag = 0, channels = 0, bits = 0, block_align = 0, rate = 0;
+  if (fread(hdr, 1, 12, fp) != 12 || memcmp(hdr, "RIFF", 4) || memcmp(hdr + 8, "WAVE", 4)) {
+    fclose(fp);
+    return WAV_ENOTWAVE;
+  }
+  unsigned tag = 0;
   bool have_fmt = false;
+  int rc = WAV_ENOAUDIO;
   while (fread(ck, 1, 8, fp) == 8) {
     const uint32_t sz = rd32(ck + 4);
     if (!memcmp(ck, "fmt ", 4)) {
@@ -246,62 +259,135 @@ extern "C" int scan_file(const char *file, unsigned index) {
       if (sz > n) fseek(fp, (long)(sz - n), SEEK_CUR);
       if (sz & 1) fseek(fp, 1, SEEK_CUR);
       tag = rd16(fmt);
-      channels = rd16(fmt + 2);
-      rate = rd32(fmt + 4);
-      block_align = rd16(fmt + 12);
-      bits = rd16(fmt + 14);
+      wi->channels = rd16(fmt + 2);
+      wi->rate = rd32(fmt + 4);
+      wi->block_align = rd16(fmt + 12);
+      wi->bits = rd16(fmt + 14);
       if (tag == 0xFFFE && sz >= 26) tag = rd16(fmt + 24);  // WAVE_FORMAT_EXTENSIBLE sub-format
       have_fmt = true;
     } else if (!memcmp(ck, "data", 4)) {
-      if (!have_fmt || !channels || !block_align) break;
-      int codec;
-      if (tag == 1 && bits == 16) codec = CODEC_PCM_S16LE;
-      else if (tag == 1 && bits == 8) codec = CODEC_PCM_U8;
-      else if (tag == 1 && bits == 24) codec = CODEC_PCM_S24LE;
-      else if (tag == 1 && bits == 32) codec = CODEC_PCM_S32LE;
-      else if (tag == 3 && bits == 32) codec = CODEC_PCM_F32LE;
-      else if (tag == 3 && bits == 64) codec = CODEC_PCM_F64LE;
-      else fail("Could not find the codec: %s", file);
-      const size_t bps = bits / 8;
-      size_t total = sz / block_align;
-      std::vector<unsigned char> raw((size_t)total * block_align);
-      const size_t got = raw.empty() ? 0 : fread(raw.data(), block_align, total, fp);
-      total = got;  // truncated file: silently shortened, like scan.c:229-240
-      fclose(fp);
-      // every sample format -> interleaved S16, as swr_convert does at scan.c:442
-      std::vector<short> s16((size_t)total * channels);
-      for (size_t i = 0; i < s16.size(); ++i) {
-        const unsigned char *p = raw.data() + (i / channels) * block_align + (i % channels) * bps;
-        switch (codec) {
-          case CODEC_PCM_S16LE: s16[i] = (short)rd16(p); break;
-          case CODEC_PCM_U8: s16[i] = (short)(((int)p[0] - 0x80) * 256); break;
-          case CODEC_PCM_S24LE: {
-            const int32_t v = (int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24);
-            s16[i] = (short)(v >> 16);
-          } break;
-          case CODEC_PCM_S32LE: s16[i] = (short)((int32_t)rd32(p) >> 16); break;
-          case CODEC_PCM_F32LE: {
-            float f;
-            const uint32_t u = rd32(p);
-            memcpy(&f, &u, 4);
-            s16[i] = clip16(lrintf(f * 32768.0f));
-          } break;
-          default: {
-            double d;
-            const uint64_t u = (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32);
-            memcpy(&d, &u, 8);
-            s16[i] = clip16(lrint(d * 32768.0));
-          } break;
-        }
+      if (!have_fmt || !wi->channels || !wi->block_align) break;
+      const unsigned bits = wi->bits;
+      if (tag == 1 && bits == 16) wi->codec = CODEC_PCM_S16LE;
+      else if (tag == 1 && bits == 8) wi->codec = CODEC_PCM_U8;
+      else if (tag == 1 && bits == 24) wi->codec = CODEC_PCM_S24LE;
+      else if (tag == 1 && bits == 32) wi->codec = CODEC_PCM_S32LE;
+      else if (tag == 3 && bits == 32) wi->codec = CODEC_PCM_F32LE;
+      else if (tag == 3 && bits == 64) wi->codec = CODEC_PCM_F64LE;
+      else {
+        rc = WAV_ECODEC;
+        break;
       }
-      begin_track(index, file, "wav", codec, channels, rate, total);
-      upload_s16(g_tracks[index], s16.data());
-      return 0;
+      wi->data_off = ftell(fp);
+      wi->frames = sz / wi->block_align;
+      rc = WAV_OK;
+      break;
     } else {
       fseek(fp, (long)(sz + (sz & 1)), SEEK_CUR);
     }
   }
-  fail("Could not find audio stream: %s", file);
+  fclose(fp);
+  return rc;
+}
+
+// the data chunk -> interleaved S16, as swr_convert does for every decoded frame at
+// scan.c:442; returns the frames actually present (a truncated file is silently
+// shortened, like the packet loop at scan.c:229-240), or -1 if the file vanished
+long long wav_read_s16(const char *file, const WavInfo &wi, short *out, size_t cap_frames) {
+  FILE *fp = fopen(file, "rb");
+  if (!fp) return -1;
+  fseek(fp, wi.data_off, SEEK_SET);
+  const size_t want = wi.frames < cap_frames ? wi.frames : cap_frames;
+  const unsigned ch = wi.channels, ba = wi.block_align, bps = wi.bits / 8;
+  size_t done = 0;
+  if (wi.codec == CODEC_PCM_S16LE && ba == ch * 2) {  // already the target grid: straight read
+    done = want ? fread(out, ba, want, fp) : 0;
+    fclose(fp);
+    return (long long)done;
+  }
+  std::vector<unsigned char> raw((size_t)65536 * ba);
+  while (done < want) {
+    const size_t n = std::min<size_t>(65536, want - done);
+    const size_t got = fread(raw.data(), ba, n, fp);
+    if (!got) break;
+    short *o = out + done * ch;
+    for (size_t f = 0; f < got; ++f) {
+      const unsigned char *p = raw.data() + f * ba;
+      for (unsigned c = 0; c < ch; ++c, p += bps) {
+        short v;
+        switch (wi.codec) {
+          case CODEC_PCM_S16LE: v = (short)rd16(p); break;
+          case CODEC_PCM_U8: v = (short)(((int)p[0] - 0x80) * 256); break;
+          case CODEC_PCM_S24LE:
+            v = (short)((int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24) >> 16);
+            break;
+          case CODEC_PCM_S32LE: v = (short)((int32_t)rd32(p) >> 16); break;
+          case CODEC_PCM_F32LE: {
+            float x;
+            const uint32_t u = rd32(p);
+            memcpy(&x, &u, 4);
+            v = clip16(lrintf(x * 32768.0f));
+          } break;
+          default: {
+            double x;
+            const uint64_t u = (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32);
+            memcpy(&x, &u, 8);
+            v = clip16(lrint(x * 32768.0));
+          } break;
+        }
+        o[f * ch + c] = v;
+      }
+    }
+    done += got;
+    if (got < n) break;
+  }
+  fclose(fp);
+  return (long long)done;
+}
+
+}  // namespace
+
+extern "C" int scan_wav_probe(const char *file, scan_wav_info *out) {
+  if (!file || !out) return WAV_EOPEN;
+  WavInfo wi;
+  const int rc = wav_probe(file, &wi);
+  if (rc) return rc;
+  out->codec_id = wi.codec;
+  out->channels = wi.channels;
+  out->rate = wi.rate;
+  out->bits = wi.bits;
+  out->frames = wi.frames;
+  return 0;
+}
+
+extern "C" long long scan_wav_read_s16(const char *file, short *out, size_t cap_frames) {
+  if (!file || (!out && cap_frames)) return WAV_EOPEN;
+  WavInfo wi;
+  const int rc = wav_probe(file, &wi);
+  if (rc) return rc;
+  const long long got = wav_read_s16(file, wi, out, cap_frames);
+  return got < 0 ? (long long)WAV_EOPEN : got;
+}
+
+extern "C" int scan_file(const char *file, unsigned index) {
+  if ((int)index >= g_nb) {
+    errmsg("Index too high");
+    return -1;
+  }
+  WavInfo wi;
+  switch (wav_probe(file, &wi)) {
+    case WAV_OK: break;
+    case WAV_EOPEN: fail("Could not open input: %s", file);
+    case WAV_ENOTWAVE: fail("Could not find stream info: %s (only RIFF/WAVE is read without FFmpeg)", file);
+    case WAV_ECODEC: fail("Could not find the codec: %s", file);
+    default: fail("Could not find audio stream: %s", file);
+  }
+  std::vector<short> s16(wi.frames * wi.channels);
+  const long long got = wav_read_s16(file, wi, s16.data(), wi.frames);
+  if (got < 0) fail("Could not open input: %s", file);
+  begin_track(index, file, "wav", wi.codec, wi.channels, wi.rate, (size_t)got);
+  upload_s16(g_tracks[index], s16.data());
+  return 0;
 }
 
 extern "C" scan_result *scan_get_track_result(unsigned index, double pre_gain) {

@@ -28,8 +28,13 @@ SCAN_SYMBOLS = [
     "scan_album_has_different_containers", "scan_album_has_opus", "scan_file",
     "scan_get_track_result", "scan_get_album_peak", "scan_set_album_result",
     "scan_get_album_result", "scan_set_device", "scan_pcm_s16", "scan_pcm_f32",
-    "scan_pcm_f32_device", "scan_set_codec",
+    "scan_pcm_f32_device", "scan_set_codec", "scan_wav_probe", "scan_wav_read_s16",
 ]
+
+
+class ScanWavInfo(C.Structure):
+    _fields_ = [("codec_id", C.c_int), ("channels", C.c_uint), ("rate", C.c_uint), ("bits", C.c_uint),
+                ("frames", C.c_size_t)]
 
 _L = None
 _libc = C.CDLL(None)
@@ -55,6 +60,9 @@ def _lib_scan():
         L.scan_pcm_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
         L.scan_pcm_f32_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
         L.scan_set_codec.argtypes = [C.c_uint, C.c_int, C.c_char_p]
+        L.scan_wav_probe.argtypes = [C.c_char_p, C.POINTER(ScanWavInfo)]
+        L.scan_wav_read_s16.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
+        L.scan_wav_read_s16.restype = C.c_longlong
         _L = L
     return _L
 
@@ -89,6 +97,27 @@ def scan_pcm(pcm, rate, index):
     fn = L.scan_pcm_s16 if pcm.dtype == np.int16 else L.scan_pcm_f32
     assert pcm.dtype in (np.int16, np.float32)
     return fn(pcm.ctypes.data, pcm.shape[0], pcm.shape[1], int(rate), int(index))
+
+
+WAV_ERRORS = {-1: "Could not open input", -2: "Could not find stream info (not RIFF/WAVE)",
+              -3: "Could not find the codec", -4: "Could not find audio stream"}
+
+
+def scan_wav_probe(path):
+    """Header of a RIFF/WAVE file: dict(codec_id, channels, rate, bits, frames); OSError otherwise."""
+    wi = ScanWavInfo()
+    rc = _lib_scan().scan_wav_probe(str(path).encode(), C.byref(wi))
+    if rc:
+        raise OSError("%s: %s" % (WAV_ERRORS.get(rc, "error %d" % rc), path))
+    return dict(codec_id=wi.codec_id, channels=wi.channels, rate=wi.rate, bits=wi.bits, frames=wi.frames)
+
+
+def scan_wav_read_s16(path, out_ptr, cap_frames):
+    """Reads the data chunk as interleaved S16 into host memory at out_ptr; returns frames read."""
+    n = _lib_scan().scan_wav_read_s16(str(path).encode(), out_ptr, int(cap_frames))
+    if n < 0:
+        raise OSError("%s: %s" % (WAV_ERRORS.get(int(n), "error %d" % n), path))
+    return int(n)
 
 
 def scan_set_codec(index, codec_id, container=None):
