@@ -66,6 +66,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return __shfl(v, LGD_WAVE - 1, LGD_WAVE);
 }
 
+// two adjacent LDS dwords from two separate VGPRs.  Inline asm: the compiler does not
+// count it in lgkmcnt, so the caller drains with s_waitcnt lgkmcnt(0) before the barrier.
+__device__ __forceinline__ void lgd_lds_write2(float *p, float a, float b) {
+  const unsigned off = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)p;
+  asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(off), "v"(a), "v"(b) : "memory");
+}
+
 // lane l <- lane l-1, lane 0 <- fill: DPP wave_shr:1 (a VALU move, no LDS round trip;
 // lanes without a source keep `old`)
 __device__ __forceinline__ double lgd_wave_shr1(double v, double fill) {
@@ -235,13 +242,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       } else if constexpr (G == 1 && LL::PAD == 0) {                                     \
         *reinterpret_cast<f32x4 *>(lds + 4 * (idx_)) = (v_);                             \
       } else if constexpr (G == 2 && LL::PAD == 0) {                                     \
-        /* four scalar stores: hipcc pairs them into two ds_write2_b32 (data from two   */ \
-        /* separate VGPRs), so the de-interleave costs no register shuffling           */ \
+        /* two ds_write2_b32, each taking its two dwords from two separate VGPRs: the   */ \
+        /* de-interleave costs no register shuffling (left to itself hipcc merges the   */ \
+        /* stores into 64-bit ones and pays four v_mov per vector to pair the data)     */ \
         const int jj_ = 2 * (idx_);                                                      \
-        lds[jj_] = (v_).x;                                                               \
-        lds[jj_ + 1] = (v_).z;                                                           \
-        lds[PLANE + jj_] = (v_).y;                                                       \
-        lds[PLANE + jj_ + 1] = (v_).w;                                                   \
+        lgd_lds_write2(lds + jj_, (v_).x, (v_).z);                                       \
+        lgd_lds_write2(lds + PLANE + jj_, (v_).y, (v_).w);                               \
       } else {                                                                           \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                               \
           const int i_ = 4 * (idx_) + e_;                                                \
@@ -258,6 +264,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         const int idx = tid + nthreads * i;
         if (LGD_VEC_ALWAYS(i) || idx < nvec) LGD_STORE_VEC(idx, pf[i]);
       }
+      if constexpr (LL::PLANAR && G == 2 && LL::PAD == 0)
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the asm stores above
     } else if (grouped) {
       // a channel group of a wide stream: gather [frame][ch0 .. ch0 + nch) float by float
       const gflt_ptr gp = (gflt_ptr)sg.pcm;
