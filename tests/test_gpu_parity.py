@@ -265,3 +265,38 @@ def test_many_albums_in_one_plan(scanner, oracle):
     from loudgain_amd.device import LoudscanError
     with pytest.raises(LoudscanError):
         scanner.plan([to_dev(pcms[0]), to_dev(pcms[1])], 48000, albums=[1, 0])
+
+
+def test_album_of_1000_mixed_tracks(scanner, oracle):
+    """BASELINE.json configs[3]/[4] in shape: one album of 1000 tracks, mixed rates
+    (44.1 / 48 / 96 / 192 kHz) and layouts (mono / stereo / 5.1), durations 0.3 .. 4 s so
+    that the oracle finishes in seconds.  Every track and the album against the oracle."""
+    rng = np.random.default_rng(1000)
+    rates = [44100, 48000, 96000, 192000]
+    chans = [1, 2, 2, 2, 6]
+    protos = {}
+    specs = []
+    for i in range(1000):
+        rate = rates[int(rng.integers(len(rates)))]
+        ch = chans[int(rng.integers(len(chans)))]
+        secs = float(rng.uniform(0.3, 4.0)) * (0.5 if rate >= 96000 else 1.0)
+        gain = float(10.0 ** (rng.uniform(-40.0, 0.0) / 20.0))
+        specs.append((rate, ch, int(rate * secs), gain))
+    pcms = []
+    for rate, ch, frames, gain in specs:
+        key = (rate, ch)
+        if key not in protos:   # one 4 s prototype per (rate, layout); tracks are gain-scaled cuts of it
+            protos[key] = synth.track_numpy(int(rate * 4.0), ch, rate, seed=rate % 1000 + ch, step_s=0.7)
+        off = int(rng.integers(0, protos[key].shape[0] - frames + 1))
+        pcms.append(synth.snap_s16_numpy(protos[key][off:off + frames] * gain))
+    tracks, album = scanner.scan([to_dev(p) for p in pcms], [s[0] for s in specs], album=True)
+    refs = [oracle.scan_track(p, s[0]) for p, s in zip(pcms, specs)]
+    for got, ref, s in zip(tracks, refs, specs):
+        check_track(got, ref, rate=s[0])
+    states = [r["state"] for r in refs]
+    det = oracle.gating_detail(states)
+    assert album["n_abs"] == det["n_abs"] and album["n_rel"] == det["n_rel"]
+    assert abs(album["loudness"] - oracle.album_loudness(states)) <= 1e-6
+    assert abs(album["lra"] - oracle.album_lra(states)) <= 1e-6
+    assert abs(album["peak"] - max(r["peak"] for r in refs)) <= 1e-4
+    assert album["n_st"] == sum(r["n_st"] for r in refs)
