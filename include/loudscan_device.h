@@ -71,6 +71,8 @@ typedef struct {
   uint64_t n_rel;        /* blocks >= relative gate */
   uint64_t n_st_blocks;  /* 3 s blocks evaluated */
   uint64_t n_st;         /* 3 s blocks >= absolute gate */
+  double max_momentary;  /* LUFS of the loudest 400 ms window on the 100 ms grid (-HUGE_VAL: none) */
+  double max_shortterm;  /* LUFS of the loudest 3 s window on the 100 ms grid (-HUGE_VAL: none) */
 } lgd_track_result;
 
 typedef struct {

@@ -20,7 +20,8 @@ class LgdTrackResult(C.Structure):
                 ("sample_peak", C.c_double), ("true_peak", C.c_double),
                 ("rel_threshold", C.c_double), ("sum_abs", C.c_double), ("sum_rel", C.c_double),
                 ("n_blocks", C.c_uint64), ("n_abs", C.c_uint64), ("n_rel", C.c_uint64),
-                ("n_st_blocks", C.c_uint64), ("n_st", C.c_uint64)]
+                ("n_st_blocks", C.c_uint64), ("n_st", C.c_uint64),
+                ("max_momentary", C.c_double), ("max_shortterm", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

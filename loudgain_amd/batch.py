@@ -189,7 +189,8 @@ class LibraryScanner:
             a_gain = -18.0 - a["loudness"] + self.pre_gain if have_album else 0.0   # scan.c:393
             for row, r in rows:
                 t = dict(file=row[1], frames=row[4], channels=row[2]["channels"], rate=row[2]["rate"],
-                         codec_id=row[2]["codec_id"], loudness=r["loudness"], lra=r["lra"], peak=r["peak"])
+                         codec_id=row[2]["codec_id"], loudness=r["loudness"], lra=r["lra"], peak=r["peak"],
+                         max_momentary=r["max_momentary"], max_shortterm=r["max_shortterm"])
                 if np.isfinite(r["loudness"]):
                     # loudgain.c:323-379, the -k (clip prevention) / -K logic of an album run
                     g = _gain.apply_clip_logic(-18.0 - r["loudness"] + self.pre_gain, r["peak"], a_gain,

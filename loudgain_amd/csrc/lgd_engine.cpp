@@ -28,8 +28,8 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
                                                 const LgdTrackMeta *meta, int n_tracks,
                                                 const double *E, double *Z, double *st,
                                                 const float *peaks, double *p1, double *p2,
-                                                double *res, double abs_gate, double rel_factor,
-                                                int do_tp, hipStream_t s);
+                                                double *pmax_s, double *res, double abs_gate,
+                                                double rel_factor, int do_tp, hipStream_t s);
 extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
                                      double minus20, hipStream_t s);
 extern "C" hipError_t lgd_launch_album_part1(const double *res, const LgdAlbumMeta *albums,
@@ -219,7 +219,7 @@ struct lgd_ctx {
   // alternate between the two sets and between two streams (see lgd_execute).
   struct WorkSet {
     double *d_E = nullptr, *d_Z = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
-    double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr;  // per-slice gating partials
+    double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr, *d_pmax = nullptr;  // per-slice partials
     // album: record 1 = {sum_abs, n_abs, peak, n_st | st energies | 0-padding}, record 2 =
     // {sum_rel, n_rel} are what ranks exchange; d_st points into record 1; part1 = folded heads
     // (single-GPU plans may hold many albums: heads / part1 / rec2 / album are per album)
@@ -233,7 +233,7 @@ struct lgd_ctx {
     LgdRange *h_album_range = nullptr;  // pinned
     size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_segs = 0,
            cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0, cap_rec1 = 0, cap_album = 0,
-           cap_part1 = 0, cap_rec2 = 0, cap_heads = 0, cap_album_ranges = 0;
+           cap_part1 = 0, cap_rec2 = 0, cap_heads = 0, cap_album_ranges = 0, cap_pmax = 0;
     hipEvent_t ev_scan = nullptr, ev_done = nullptr;  // ev_scan: caller-stream marker for the side stream
     hipEvent_t ev_album = nullptr;  // end of a caller-driven album stage 3 on this set
     bool busy = false, album_pending = false;
@@ -313,7 +313,7 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
   for (auto &w : c->ws) {
     void *ptrs[] = {w.d_E, w.d_Z, w.d_rec1, w.d_res, w.d_album, w.d_part1, w.d_rec2, w.d_peaks,
                     w.d_segs, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a, w.d_heads,
-                    w.d_album_ranges};
+                    w.d_album_ranges, w.d_pmax};
     for (void *p : ptrs)
       if (p) (void)hipFree(p);
     if (w.h_album_range) (void)hipHostFree(w.h_album_range);
@@ -562,6 +562,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if ((rc = ensure(&w.d_p1, &w.cap_p1, 4 * c->slices.size()))) return rc;
     if ((rc = ensure(&w.d_p2, &w.cap_p2, 2 * c->slices.size()))) return rc;
     if ((rc = ensure(&w.d_p2a, &w.cap_p2a, 2 * c->slices.size()))) return rc;
+    if ((rc = ensure(&w.d_pmax, &w.cap_pmax, c->slices.size()))) return rc;
     if ((rc = ensure(&w.d_rec1, &w.cap_rec1, (size_t)c->rec1_len))) return rc;
     HIPCHK(hipMemset(w.d_rec1, 0, (size_t)c->rec1_len * sizeof(double)));  // the padding stays 0
     w.d_st = w.d_rec1 + 4;
@@ -714,7 +715,7 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   }
   if (c->p_timing) HIPCHK(hipEventRecord(ev[1], s));
   HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, w.d_E, w.d_Z,
-                                   w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_res, c->abs_gate,
+                                   w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_pmax, w.d_res, c->abs_gate,
                                    c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
   HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, s));
   c->executed = true;
@@ -769,6 +770,8 @@ extern "C" int lgd_fetch(lgd_ctx *c, lgd_track_result *out, lgd_album_result *al
       o.n_rel = (uint64_t)p[LGR_NREL];
       o.n_st_blocks = (uint64_t)p[LGR_NSTBLK];
       o.n_st = (uint64_t)p[LGR_NST];
+      o.max_momentary = p[LGR_MAX_M];
+      o.max_shortterm = p[LGR_MAX_S];
     }
   }
   if (album) {

@@ -61,11 +61,12 @@ __device__ __forceinline__ double energy_to_loudness(double e) {
 }
 
 // ---- pass 1: 400 ms block energies (E5), 3 s block energies (E6), absolute gate
-// p1[slice] = { n_abs, sum_abs, n_st, - }
+// p1[slice] = { n_abs, sum_abs, n_st, max 400 ms energy }; pmax_s[slice] = max 3 s energy on
+// the 100 ms grid (windows ending inside the slice)
 __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
     const LgdSlice *__restrict__ slices, const LgdTrackMeta *__restrict__ meta,
     const double *__restrict__ E_all, double *__restrict__ Z_all, double *__restrict__ st_all,
-    double *__restrict__ p1, double abs_gate) {
+    double *__restrict__ p1, double *__restrict__ pmax_s, double abs_gate) {
   LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
   const LgdSlice sl = slices[blockIdx.x];
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
   const int j1 = min(sl.j0 + LGD_SLICE, nblk);
   // divide like the reference does (sum /= frames_per_block), not by a reciprocal
   const double len4 = 4.0 * (double)m.s100, len30 = 30.0 * (double)m.s100;
-  double cnt = 0.0, sum = 0.0, cst = 0.0;
+  double cnt = 0.0, sum = 0.0, cst = 0.0, zmax = 0.0, smax = 0.0;
   // block energy = sum_c w_c * (channel sum over the block) / frames (A.4);
   // channels mapped EBUR128_UNUSED (weight 0) are skipped like the reference does
   for (int j = sl.j0 + tid; j < j1; j += LGD_EPI_NT) {
@@ -92,7 +93,24 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
     }
     const double zj = s / len4;
     Z[j] = zj;
+    zmax = fmax(zmax, zj);
     if (zj >= abs_gate) { cnt += 1.0; sum += zj; }
+  }
+  // largest 3 s energy on the 100 ms grid: window jj covers sub-blocks [jj, jj + 30); the
+  // running sum per thread is rebuilt every hop from the 30 values (exact, order-fixed)
+  for (int jj = sl.j0 + tid; jj < min(sl.j0 + LGD_SLICE, m.n_sb - 29); jj += LGD_EPI_NT) {
+    double s = 0.0;
+    for (int ch = 0; ch < m.nch; ++ch) {
+      const double w = lgd_channel_weight(ch, m.nch);
+      if (w == 0.0) continue;
+      const double *p = E + (size_t)ch * m.n_sb + jj;
+      double cs = 0.0;
+#pragma unroll 6
+      for (int i = 0; i < 30; ++i) cs += p[i];
+      if (w != 1.0) cs *= w;
+      s += cs;
+    }
+    smax = fmax(smax, s / len30);
   }
   // short-term block kk ends at sub-block 10 kk + 30; it belongs to the slice
   // that holds 400 ms block 10 kk
@@ -117,9 +135,12 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
   cnt = block_sum_f64<LGD_EPI_NT>(cnt, sh);
   sum = block_sum_f64<LGD_EPI_NT>(sum, sh);
   cst = block_sum_f64<LGD_EPI_NT>(cst, sh);
+  zmax = block_max_f64<LGD_EPI_NT>(zmax, sh);
+  smax = block_max_f64<LGD_EPI_NT>(smax, sh);
   if (tid == 0) {
     double *o = p1 + 4 * (size_t)blockIdx.x;
-    o[0] = cnt; o[1] = sum; o[2] = cst; o[3] = 0.0;
+    o[0] = cnt; o[1] = sum; o[2] = cst; o[3] = zmax;
+    pmax_s[blockIdx.x] = smax;
   }
 }
 
@@ -179,22 +200,26 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass2(
 // ---- per-track result record (E7 loudness, E9 peaks, counts) ----------------
 __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
     const LgdTrackMeta *__restrict__ meta, const double *__restrict__ p1,
-    const double *__restrict__ p2, const float *__restrict__ peaks, double *__restrict__ res_all,
-    double rel_factor, int do_tp) {
+    const double *__restrict__ p2, const double *__restrict__ pmax_s,
+    const float *__restrict__ peaks, double *__restrict__ res_all, double rel_factor, int do_tp) {
   LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
   const LgdTrackMeta m = meta[blockIdx.x];
   double *res = res_all + (size_t)blockIdx.x * LGR_STRIDE;
   const int tid = threadIdx.x;
-  double a = 0.0, b = 0.0, c = 0.0, d = 0.0, e = 0.0;
+  double a = 0.0, b = 0.0, c = 0.0, d = 0.0, e = 0.0, mm = 0.0, ms = 0.0;
   for (int i = tid; i < m.n_slices; i += LGD_EPI_NT) {
     const size_t s = (size_t)(m.slice_off + i);
     a += p1[4 * s + 0];
     b += p1[4 * s + 1];
     c += p1[4 * s + 2];
+    mm = fmax(mm, p1[4 * s + 3]);
+    ms = fmax(ms, pmax_s[s]);
     d += p2[2 * s + 0];
     e += p2[2 * s + 1];
   }
+  mm = block_max_f64<LGD_EPI_NT>(mm, sh);
+  ms = block_max_f64<LGD_EPI_NT>(ms, sh);
   const double n_abs = block_sum_f64<LGD_EPI_NT>(a, sh);
   const double sum_abs = block_sum_f64<LGD_EPI_NT>(b, sh);
   const double n_st = block_sum_f64<LGD_EPI_NT>(c, sh);
@@ -216,6 +241,8 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
       thr *= rel_factor;
     }
     res[LGR_LOUDNESS] = n_rel > 0.0 ? energy_to_loudness(sum_rel / n_rel) : -HUGE_VAL;
+    res[LGR_MAX_M] = mm > 0.0 ? energy_to_loudness(mm) : -HUGE_VAL;
+    res[LGR_MAX_S] = ms > 0.0 ? energy_to_loudness(ms) : -HUGE_VAL;
     res[LGR_PEAK] = do_tp ? fmax(sp, tp) : sp;
     res[LGR_SPEAK] = sp;
     res[LGR_TPEAK] = do_tp ? tp : 0.0;
@@ -433,17 +460,17 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
                                                 const LgdTrackMeta *meta, int n_tracks,
                                                 const double *E, double *Z, double *st,
                                                 const float *peaks, double *p1, double *p2,
-                                                double *res, double abs_gate, double rel_factor,
-                                                int do_tp, hipStream_t s) {
+                                                double *pmax_s, double *res, double abs_gate,
+                                                double rel_factor, int do_tp, hipStream_t s) {
   if (n_tracks <= 0) return hipSuccess;
   if (n_slices > 0) {
     hipLaunchKernelGGL(lgd_gate_pass1, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, E, Z, st,
-                       p1, abs_gate);
+                       p1, pmax_s, abs_gate);
     hipLaunchKernelGGL(lgd_gate_pass2, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, Z, p1, p2,
                        (const double *)nullptr, 0, 0LL, abs_gate, rel_factor);
   }
-  hipLaunchKernelGGL(lgd_track_final, dim3(n_tracks), dim3(LGD_EPI_NT), 0, s, meta, p1, p2, peaks, res,
-                     rel_factor, do_tp);
+  hipLaunchKernelGGL(lgd_track_final, dim3(n_tracks), dim3(LGD_EPI_NT), 0, s, meta, p1, p2, pmax_s, peaks,
+                     res, rel_factor, do_tp);
   return hipGetLastError();
 }
 

@@ -115,6 +115,6 @@ static inline LGD_HD double lgd_channel_weight(int ch, int nch) {
 // per-track device result: 16 doubles (counts are integer-valued doubles)
 enum {
   LGR_LOUDNESS = 0, LGR_LRA, LGR_PEAK, LGR_SPEAK, LGR_TPEAK, LGR_THR, LGR_SUM_ABS,
-  LGR_SUM_REL, LGR_NBLK, LGR_NABS, LGR_NREL, LGR_NSTBLK, LGR_NST, LGR_ALB_SUM_REL,
-  LGR_ALB_NREL, LGR_SPARE, LGR_STRIDE
+  LGR_SUM_REL, LGR_NBLK, LGR_NABS, LGR_NREL, LGR_NSTBLK, LGR_NST, LGR_MAX_M,
+  LGR_MAX_S, LGR_SPARE, LGR_STRIDE
 };

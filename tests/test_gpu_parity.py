@@ -300,3 +300,27 @@ def test_album_of_1000_mixed_tracks(scanner, oracle):
     assert abs(album["lra"] - oracle.album_lra(states)) <= 1e-6
     assert abs(album["peak"] - max(r["peak"] for r in refs)) <= 1e-4
     assert album["n_st"] == sum(r["n_st"] for r in refs)
+
+
+def test_max_momentary_and_shortterm(scanner):
+    """Loudest 400 ms / 3 s window on the 100 ms grid: against a numpy sliding sum over the
+    (oracle-checked) 100 ms sub-block energies, and EBU Tech 3341's -23 dBFS 1 kHz stereo
+    sine, for which M = S = I = -23.0 LUFS."""
+    rate = 48000
+    pcm = synth.track_numpy(rate * 21, 2, rate, seed=31, step_s=2.5)
+    short = synth.track_numpy(int(rate * 1.7), 2, rate, seed=32)            # has 400 ms windows, no 3 s window
+    t = np.arange(rate * 8)
+    sine = np.repeat((10 ** (-23 / 20) * np.sin(2 * np.pi * 1000 * t / rate)).astype(np.float32)[:, None], 2, 1)
+    tracks, _ = scanner.scan([to_dev(pcm), to_dev(short), to_dev(sine)], rate)
+    for i, (x, tr) in enumerate(zip((pcm, short, sine), tracks)):
+        e = scanner.subblock_energies(i)                                   # sum_c w_c sum y^2 per 100 ms
+        s100 = rate // 10
+        m = np.convolve(e, np.ones(4), "valid") / (4 * s100) if e.size >= 4 else np.zeros(0)
+        s = np.convolve(e, np.ones(30), "valid") / (30 * s100) if e.size >= 30 else np.zeros(0)
+        want_m = 10 * np.log10(m.max()) - 0.691 if m.size else -np.inf
+        want_s = 10 * np.log10(s.max()) - 0.691 if s.size else -np.inf
+        assert abs(tr["max_momentary"] - want_m) <= 1e-9 or tr["max_momentary"] == want_m
+        assert abs(tr["max_shortterm"] - want_s) <= 1e-9 or tr["max_shortterm"] == want_s
+    assert tracks[1]["max_shortterm"] == -np.inf and np.isfinite(tracks[1]["max_momentary"])
+    assert abs(tracks[2]["max_momentary"] + 23.0) <= 0.1 and abs(tracks[2]["max_shortterm"] + 23.0) <= 0.1
+    assert abs(tracks[2]["loudness"] + 23.0) <= 0.1
