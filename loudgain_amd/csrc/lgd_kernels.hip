@@ -232,6 +232,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 
   for (int k = -sg.n_warm_tiles; k < n_main; ++k) {
     const long long tb = sg.f0 + (long long)k * K::TILE_F;  // first frame of the tile
+    __builtin_amdgcn_s_setprio(2);  // staging: get the stores, the barrier and the next loads out first
     __syncthreads();  // every wave is done reading the previous tile
     // LDS slot of frame f of a plane (planar layouts): PO_W + f + floor(f / C) * PAD,
     // written in terms of the vector's own frame slot jj = f + HALO + shift / G
@@ -295,6 +296,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 #undef LGD_STORE_VEC
     __syncthreads();
     if (k + 1 < n_main) LGD_PREFETCH(k + 1); else pf_valid = false;
+    __builtin_amdgcn_s_setprio(0);
 
     // this lane's chunk of this wave's channel: frames [tb + lane*C, +C), frame
     // stride nch floats, streamed from LDS U frames at a time
@@ -430,6 +432,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         }
       }
 
+      // (latency-bound section: issue priority over the SIMD's other wave, which is most
+      // likely streaming through phase A or C)
+      __builtin_amdgcn_s_setprio(2);
       // ---- B: inject the carry at lane 0, then Kogge-Stone over 64 lanes.  The
       // transition is block lower triangular: rows 0,1 see columns 0,1 only. ----
       if (lane == 0) {
@@ -499,6 +504,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         ps[h][0] = sv[h][2] * dcg;
         ps[h][1] = sv[h][3] * dcg;
       }
+      __builtin_amdgcn_s_setprio(0);
     }
 
     if (k < 0) continue;  // warm-up tile: only the carry matters
