@@ -182,6 +182,14 @@ static void design_interp(int factor, float tp[36]) {
   if (factor == 4) {
     for (int t = 0; t < 12; ++t) tp[t] = (float)br[1][t];
     for (int t = 0; t < 6; ++t) tp[12 + t] = (float)br[2][t];
+    // phase 3 is phase 1 mirrored: with a_k = x[n-k] + x[n-11+k], b_k = x[n-k] - x[n-11+k]
+    // the pair is y1 + y3 = sum (c1[k] + c1[11-k]) a_k and y1 - y3 = sum (c1[k] - c1[11-k]) b_k,
+    // and max(|y1|, |y3|) = (|y1 + y3| + |y1 - y3|) / 2: the kernel gets the halved
+    // sum / difference coefficients as pairs (tp[18 + 2k], tp[19 + 2k])
+    for (int k = 0; k < 6; ++k) {
+      tp[18 + 2 * k] = (float)(0.5 * (br[1][k] + br[1][11 - k]));
+      tp[19 + 2 * k] = (float)(0.5 * (br[1][k] - br[1][11 - k]));
+    }
   } else {
     for (int t = 0; t < 12; ++t) tp[t] = (float)br[1][t];
   }

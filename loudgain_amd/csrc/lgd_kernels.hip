@@ -39,6 +39,7 @@
 #define LGD_WAVE 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Pointers that arrive inside a descriptor in memory lose their address space and
 // compile to flat_* accesses, which count in lgkmcnt too: every LDS wait would
 // then also wait for the prefetched tile.  These casts make them global_*.
@@ -191,6 +192,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // symmetric: 4x phase 3 mirrors phase 1, phase 2 and the 2x phase mirror
   // themselves) -> 18 / 12 SGPRs instead of 36 / 24
   float tpa[12 + 1], tpb[6 + 1];
+  f32x2 tpsd[6 + 1];  // 4x: halved (sum, difference) coefficients of the mirrored phase pair
+#pragma unroll
+  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpsd[i] = (f32x2){F.tp[18 + 2 * i], F.tp[19 + 2 * i]};
 #pragma unroll
   for (int i = 0; i < (TP ? 12 : 0); ++i) tpa[i] = F.tp[i];
 #pragma unroll
@@ -538,19 +542,25 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     do {                                                                                \
       _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) pk_s = fmaxf(pk_s, fabsf(wv[HX + u_])); \
       if constexpr (TP == 4) {                                                          \
-        float o1_[U], o2_[U], o3_[U];                                                   \
-        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) o1_[u_] = o2_[u_] = o3_[u_] = 0.f; \
-        _Pragma("unroll") for (int t_ = 0; t_ < 12; ++t_) {                             \
-          const float c1_ = tpa[t_], c3_ = tpa[11 - t_], c2_ = tpb[t_ < 6 ? t_ : 11 - t_]; \
+        /* phases 1 and 3 mirror each other, phase 2 is symmetric: per output sample six  */ \
+        /* (sum, difference) pairs of window samples feed one packed FMA for (y1 + y3,    */ \
+        /* y1 - y3) / 2 and one FMA for y2 -- 24 instructions instead of 36 FMAs;         */ \
+        /* max(|y1|, |y3|) = |y1 + y3| / 2 + |y1 - y3| / 2                                  */ \
+        f32x2 sd_[U];                                                                   \
+        float o2_[U];                                                                   \
+        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) { sd_[u_] = (f32x2){0.f, 0.f}; o2_[u_] = 0.f; } \
+        _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) {                              \
+          const f32x2 csd_ = tpsd[k_];                                                  \
+          const float c2_ = tpb[k_];                                                    \
           _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                            \
-            const float xv_ = wv[HX + u_ - t_];                                         \
-            o1_[u_] = fmaf(c1_, xv_, o1_[u_]);                                          \
-            o2_[u_] = fmaf(c2_, xv_, o2_[u_]);                                          \
-            o3_[u_] = fmaf(c3_, xv_, o3_[u_]);                                          \
+            const float xa_ = wv[HX + u_ - k_], xb_ = wv[u_ + k_];                      \
+            const f32x2 ab_ = (f32x2){xa_ + xb_, xa_ - xb_};                            \
+            sd_[u_] = __builtin_elementwise_fma(csd_, ab_, sd_[u_]);                    \
+            o2_[u_] = fmaf(c2_, ab_.x, o2_[u_]);                                        \
           }                                                                             \
         }                                                                               \
         _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                              \
-          float m_ = fmaxf(fmaxf(fabsf(o1_[u_]), fabsf(o2_[u_])), fabsf(o3_[u_]));      \
+          float m_ = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));        \
           if (tail) m_ = ((jb) + u_ < nvalid) ? m_ : 0.f;                               \
           pk_t = fmaxf(pk_t, m_);                                                       \
         }                                                                               \
