@@ -565,12 +565,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           pk_t = fmaxf(pk_t, m_);                                                       \
         }                                                                               \
       } else if constexpr (TP == 2) {                                                   \
+        /* the one non-trivial 2x phase is symmetric: 12 sums + 12 FMAs per sample */   \
         float o1_[U];                                                                   \
         _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) o1_[u_] = 0.f;                 \
-        _Pragma("unroll") for (int t_ = 0; t_ < 24; ++t_) {                             \
-          const float c1_ = tpa[t_ < 12 ? t_ : 23 - t_];                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < 12; ++k_) {                             \
+          const float c1_ = tpa[k_];                                                    \
           _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                              \
-            o1_[u_] = fmaf(c1_, wv[HX + u_ - t_], o1_[u_]);                             \
+            o1_[u_] = fmaf(c1_, wv[HX + u_ - k_] + wv[u_ + k_], o1_[u_]);               \
         }                                                                               \
         _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                              \
           float m_ = fabsf(o1_[u_]);                                                    \
