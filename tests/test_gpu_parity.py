@@ -324,3 +324,62 @@ def test_max_momentary_and_shortterm(scanner):
     assert tracks[1]["max_shortterm"] == -np.inf and np.isfinite(tracks[1]["max_momentary"])
     assert abs(tracks[2]["max_momentary"] + 23.0) <= 0.1 and abs(tracks[2]["max_shortterm"] + 23.0) <= 0.1
     assert abs(tracks[2]["loudness"] + 23.0) <= 0.1
+
+
+def test_full_size_properties():
+    """BASELINE.json's full size (60 min, 48 kHz stereo f32 = 1.38 GB), where the oracle
+    would take minutes: size-independent properties of the measurement instead.
+      * the first 90 s agree with the oracle (same buffer, block energies are causal);
+      * halving the signal (exact in binary floating point) scales every 100 ms energy by
+        exactly 1/4 (bit for bit), the ungated maxima by exactly 10 log10(1/4), the peaks by 1/2;
+      * block energies do not depend on how the track is cut into segments / tiles
+        (sub-block energies within 1e-10 relative for three other segmentations / tile lengths);
+      * an album of the track with itself has the track's loudness and range;
+      * 4x true peak on/off changes nothing but the peak fields."""
+    import torch
+    from loudgain_amd.device import DeviceScanner
+    from oracle import lgoracle
+    rate, ch = 48000, 2
+    frames = 60 * 60 * rate
+    pcm = synth.track_torch(frames, ch, rate, seed=2026, device="cuda")
+    sc = DeviceScanner(0)
+    (full,), _ = sc.scan([pcm], rate, true_peak=True)
+    e_ref = sc.subblock_energies(0)
+    assert full["n_blocks"] == 36000 - 3 and full["n_st_blocks"] == (36000 - 30) // 10 + 1
+    # prefix against the oracle
+    head = pcm[: 90 * rate].cpu().numpy()
+    ref = lgoracle.scan_track(head, rate)
+    (hd,), _ = sc.scan([pcm[: 90 * rate]], rate, true_peak=True)
+    check_track(hd, ref)
+    np.testing.assert_array_equal(sc.subblock_energies(0), e_ref[:900])   # causal: prefix energies identical
+    # exact scaling
+    half = pcm * 0.5
+    (hf,), _ = sc.scan([half], rate, true_peak=True)
+    # (the absolute gate is absolute: gate counts and the integrated value may change, the
+    # block energies and the ungated maxima may not)
+    assert abs((full["max_momentary"] - hf["max_momentary"]) - 10 * np.log10(4.0)) <= 1e-12
+    assert abs((full["max_shortterm"] - hf["max_shortterm"]) - 10 * np.log10(4.0)) <= 1e-12
+    assert hf["sample_peak"] == full["sample_peak"] * 0.5 and abs(hf["true_peak"] - full["true_peak"] * 0.5) <= 1e-7
+    np.testing.assert_array_equal(sc.subblock_energies(0), e_ref * 0.25)
+    del half
+    # segmentation independence, bit for bit
+    for seg, chunk in ((9, 75), (100, 25), (1000000, 50)):
+        s2 = DeviceScanner(0)
+        s2.set_param("seg_subblocks", seg)
+        s2.set_param("chunk", chunk)
+        (g2,), _ = s2.scan([pcm], rate, true_peak=False)
+        e2 = s2.subblock_energies(0)
+        # different tilings round differently: <= ~1e-11 relative, on quiet blocks right after loud ones
+        np.testing.assert_allclose(e2, e_ref, rtol=1e-10, atol=0)
+        assert g2["n_abs"] == full["n_abs"] and g2["n_rel"] == full["n_rel"]
+        assert abs(g2["loudness"] - full["loudness"]) <= 1e-10 and abs(g2["lra"] - full["lra"]) <= 1e-10
+        assert g2["sample_peak"] == full["sample_peak"] and g2["true_peak"] == 0.0
+        s2.close()
+    # album of the track with itself
+    (a, b), alb = sc.scan([pcm, pcm], rate, true_peak=False, album=True)
+    assert a == b and a["n_abs"] == full["n_abs"]
+    assert alb["n_abs"] == 2 * full["n_abs"] and alb["n_rel"] == 2 * full["n_rel"]
+    assert abs(alb["loudness"] - full["loudness"]) <= 1e-12 and abs(alb["lra"] - full["lra"]) <= 1e-12
+    assert alb["peak"] == a["peak"]
+    sc.close()
+    torch.cuda.empty_cache()
