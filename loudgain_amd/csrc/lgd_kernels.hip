@@ -227,8 +227,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       /* VALU address arithmetic, no per-load branches -> the loads stay batched   */   \
       const gvec_ptr src_ = (gvec_ptr)(sg.pcm + g0_);                                   \
       _Pragma("unroll") for (int i_ = 0; i_ < K::NV; ++i_) {                            \
-        const gvec_ptr src_i_ = src_ + nthreads * i_;                                   \
-        if (LGD_VEC_ALWAYS(i_) || tid + nthreads * i_ < nvec) pf[i_] = src_i_[tid];     \
+        /* the base of every vector stays a scalar (opaque to the optimiser): SGPR-base   */ \
+        /* + 32-bit lane offset addressing, no 64-bit VALU adds per load                */ \
+        gvec_ptr src_i_ = src_ + nthreads * i_;                                         \
+        asm volatile("" : "+s"(src_i_));                                                \
+        if (LGD_VEC_ALWAYS(i_) || tid + nthreads * i_ < nvec) pf[i_] = src_i_[(unsigned)tid]; \
       }                                                                                 \
     }                                                                                   \
   } while (0)
