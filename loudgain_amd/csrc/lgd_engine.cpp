@@ -242,9 +242,10 @@ struct lgd_ctx {
     size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_segs = 0,
            cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0, cap_rec1 = 0, cap_album = 0,
            cap_part1 = 0, cap_rec2 = 0, cap_heads = 0, cap_album_ranges = 0, cap_pmax = 0;
-    hipEvent_t ev_scan = nullptr, ev_done = nullptr;  // ev_scan: caller-stream marker for the side stream
+    hipEvent_t ev_scan = nullptr;   // caller-stream marker the internal stream waits for
+    hipEvent_t ev_done = nullptr;   // end of this set's scan + epilogue (lgd_album_join)
     hipEvent_t ev_album = nullptr;  // end of a caller-driven album stage 3 on this set
-    bool busy = false, album_pending = false;
+    bool album_pending = false;
   } ws[4];
   int n_sets = 1;     // 2 pipelined; 4 when the caller drives the album stages (their exchange lags the scans)
   int cur_set = 0;    // set of the last lgd_execute
@@ -562,7 +563,6 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   c->ranges.resize(n);
   for (int k = 0; k < c->n_sets; ++k) {
     lgd_ctx::WorkSet &w = c->ws[k];
-    w.busy = false;
     w.album_pending = false;
     w.lra_base = nullptr;
     if ((rc = ensure(&w.d_E, &w.cap_E, c->total_e))) return rc;
