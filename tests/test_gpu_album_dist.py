@@ -12,7 +12,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _tracks():
+def _many_tracks(n=300):
+    """BASELINE.json configs[3] in shape (many stereo tracks, one album, sharded), short tracks."""
+    from loudgain_amd import synth
+    rng = np.random.default_rng(303)
+    proto = synth.track_numpy(48000 * 5, 2, 48000, seed=77, step_s=0.6)
+    out = []
+    for i in range(n):
+        frames = int(48000 * rng.uniform(0.4, 3.0))
+        off = int(rng.integers(0, proto.shape[0] - frames + 1))
+        g = float(10.0 ** (rng.uniform(-30.0, 0.0) / 20.0))
+        out.append((synth.snap_s16_numpy(proto[off:off + frames] * g), 48000))
+    return out
+
+
+def _tracks(kind="mixed"):
+    if kind == "many":
+        return _many_tracks()
     from loudgain_amd import synth
     specs = [(48000, 2, 14.0, 1, 1.0), (48000, 2, 9.0, 2, 0.04), (44100, 1, 11.0, 3, 1.0),
              (48000, 2, 6.5, 4, 0.5), (96000, 2, 5.0, 5, 1.0), (48000, 6, 4.5, 6, 0.8), (48000, 2, 0.2, 7, 1.0)]
@@ -23,7 +39,7 @@ def _tracks():
     return out
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", kind="mixed"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -36,7 +52,7 @@ def _worker(rank, world, port, q, backend="gloo"):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    tracks = _tracks()
+    tracks = _tracks(kind)
     mine = shard_indices(len(tracks), rank, world)
     dev = [torch.from_numpy(tracks[i][0]).cuda() for i in mine]
     job = DistributedAlbumScanner(DeviceScanner(0), dev, [tracks[i][1] for i in mine],
@@ -51,22 +67,23 @@ def _worker(rank, world, port, q, backend="gloo"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,backend", [(1, "gloo"), (2, "gloo"), (3, "gloo"), (1, "nccl")])
-def test_sharded_album_matches_oracle(oracle, world, backend):
+@pytest.mark.parametrize("world,backend,kind", [(1, "gloo", "mixed"), (2, "gloo", "mixed"), (3, "gloo", "mixed"),
+                                                (1, "nccl", "mixed"), (3, "gloo", "many")])
+def test_sharded_album_matches_oracle(oracle, world, backend, kind):
     """(1, "nccl"): the RCCL calls themselves (all-reduce SUM/MAX on engine-owned HBM,
     all-gather into a tensor) with one rank, where every collective is an identity."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 2000) + world + (7 if backend == "nccl" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
+    port = 29700 + (os.getpid() % 2000) + world + (7 if backend == "nccl" else 0) + (13 if kind == "many" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    tracks = _tracks()
+    tracks = _tracks(kind)
     refs = [oracle.scan_track(p, r) for p, r in tracks]
     states = [r["state"] for r in refs]
     want_l, want_r = oracle.album_loudness(states), oracle.album_lra(states)
