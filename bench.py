@@ -192,6 +192,10 @@ def main():
                 "kernel": "lgd_scan_kernel", "kernel_ms_mean": round(ks["scan_mean_ms"], 4),
                 "kernel_ms_min": round(ks["scan_min_ms"], 4), "launches_timed": ks["n"],
                 "algorithmic_bytes_per_launch": algo_bytes,
+                # the same bytes over the wall time of one step of the timed region (scans
+                # pipelined, epilogue and launch overheads included)
+                "sustained_GBs": round(algo_bytes * world / (dt / args.steps) / 1e9 / world, 1),
+                "sustained_frac": round(algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                 "timing": ("serial launches right after the timed region (the region itself pipelines "
                            "consecutive scans on two streams)" if overlapped else "launches of the timed region"),
             },
