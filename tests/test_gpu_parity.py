@@ -383,3 +383,52 @@ def test_full_size_properties():
     assert alb["peak"] == a["peak"]
     sc.close()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+def test_fuzz_mixed_plans(scanner, oracle, seed):
+    """Random plans: 12 tracks each with random rate, layout, length (from a few frames to
+    ~25 s, clustered around the block-length edges 100 ms / 400 ms / 3 s), gain and content
+    (noise, LF tone, impulses, silence), true peak on or off, one album per plan."""
+    rng = np.random.default_rng(seed)
+    rates = [8000, 11025, 22050, 32000, 44100, 48000, 88200, 96000, 176400, 192000]
+    specs, pcms = [], []
+    for i in range(12):
+        rate = rates[int(rng.integers(len(rates)))]
+        ch = int(rng.choice([1, 2, 2, 2, 3, 5, 6, 8]))
+        edge = float(rng.choice([0.0, 0.1, 0.4, 3.0, 3.1]))
+        secs = edge + float(rng.choice([0.0, 1.0 / rate, 0.003, 0.0999, 0.1001, 0.37, 1.234, 7.7, 25.0])) \
+            * (0.3 if rate > 96000 or ch > 2 else 1.0)
+        frames = max(0, int(round(secs * rate)))
+        kind = int(rng.integers(4))
+        t = np.arange(frames)[:, None] / rate
+        if kind == 0:
+            x = rng.standard_normal((frames, ch)) * 0.2
+        elif kind == 1:
+            x = 0.7 * np.sin(2 * np.pi * float(rng.uniform(20, 200)) * t + np.arange(ch)[None, :])
+        elif kind == 2:
+            x = np.zeros((frames, ch))
+            if frames:
+                x[rng.integers(0, frames, size=min(frames, 20)), :] = rng.uniform(-1, 1, size=(min(frames, 20), 1))
+        else:
+            x = np.zeros((frames, ch))
+        x = x * float(10.0 ** (rng.uniform(-60.0, 0.0) / 20.0))
+        pcms.append(synth.snap_s16_numpy(x.astype(np.float32).reshape(frames, ch)))
+        specs.append((rate, ch, frames))
+    tp = bool(rng.integers(2))
+    tracks, album = scanner.scan([to_dev(p) if p.size else torch_empty(p.shape[1]) for p in pcms],
+                                 [s[0] for s in specs], true_peak=tp, album=True)
+    refs = [oracle.scan_track(p, s[0]) for p, s in zip(pcms, specs)]
+    for got, ref, s in zip(tracks, refs, specs):
+        check_track(got, ref, tp=tp, rate=s[0])
+    states = [r["state"] for r in refs]
+    det = oracle.gating_detail(states)
+    assert album["n_abs"] == det["n_abs"] and album["n_rel"] == det["n_rel"]
+    want = oracle.album_loudness(states)
+    assert album["loudness"] == want or abs(album["loudness"] - want) <= 1e-6
+    assert abs(album["lra"] - oracle.album_lra(states)) <= 1e-6
+
+
+def torch_empty(ch):
+    import torch
+    return torch.zeros((0, ch), dtype=torch.float32, device="cuda")
