@@ -8,17 +8,24 @@ PEAK_TOL = 1e-4      # +-0.0001 on (true) peak
 ENERGY_RTOL = 1e-9   # block energies at <= 48 kHz
 
 
-def energy_rtol(rate):
-    """Block-energy agreement that can be asked of two correct fp64 evaluations.
+def energy_rtol(rate, lf_tones=False):
+    """Block-energy agreement that can be asked of the HIP path and the oracle.
 
-    The reference runs the MERGED 4th-order filter in direct form II: its
-    numerator conv(pb, (1,-2,1)) is rounded, so the double zero at z = 1 is only
-    approximate, and its state is ~1/(1-r)^2 times the signal.  Measured against
-    long double (tools/gpu_err_probe.py) that form carries 1.6e-9 (48 kHz) to
-    4e-7 (192 kHz) of its own rounding noise on loud low-frequency material; the
-    HIP path (exact second difference, cascade state) is accurate to ~1e-13 of
-    the exact chain.  Agreement with the oracle is therefore bounded by the
-    oracle's own noise floor, which grows ~ (rate/48k)^4."""
+    The reference (libebur128, restated by the oracle) runs the MERGED 4th-order filter
+    in direct form II with the numerator conv(pb, (1,-2,1)) rounded to double: its double
+    zero at z = 1 is only approximate.  The HIP path applies the exact second difference
+    and carries a well-conditioned cascade state.
+      * broadband material: the two agree to the oracle's arithmetic noise,
+        1e-9 * max(1, (rate/48k)^4);
+      * loud tones of tens of Hz (lf_tones, the randomised plans): they differ
+        SYSTEMATICALLY, by the rounding of those merged coefficients, not by noise --
+        measured against a long-double evaluation of the reference's own coefficients
+        (tools/gpu_err_probe.py): 4.7e-10 (48 kHz), 2.0e-8 (96 kHz), 2.1e-7 (192 kHz) of the
+        block energy at 37 Hz, ~3.4x that at 20 Hz, and it scatters from rate to rate with
+        the rounding pattern: 5e-9 * (rate/48k)^4.5 covers 200 random plans with margin.
+        In loudness that is <= 1.2e-5 LU at 192 kHz against the +-0.01 LU bar."""
+    if lf_tones:
+        return max(ENERGY_RTOL, 5e-9 * (rate / 48000.0) ** 4.5)
     return ENERGY_RTOL * max(1.0, (rate / 48000.0) ** 4)
 
 
@@ -27,9 +34,9 @@ def to_dev(pcm):
     return torch.from_numpy(np.ascontiguousarray(pcm)).to("cuda")
 
 
-def check_track(got, ref, tp=True, rate=48000):
+def check_track(got, ref, tp=True, rate=48000, lf_tones=False):
     """got: lgd_track_result dict; ref: oracle.scan_track dict."""
-    rtol = energy_rtol(rate)
+    rtol = energy_rtol(rate, lf_tones)
     assert got["n_abs"] == ref["n_abs"], (got["n_abs"], ref["n_abs"])
     assert got["n_rel"] == ref["n_rel"], (got["n_rel"], ref["n_rel"])
     assert got["n_st"] == ref["n_st"], (got["n_st"], ref["n_st"])
@@ -37,8 +44,8 @@ def check_track(got, ref, tp=True, rate=48000):
         assert got["loudness"] == -math.inf
     else:
         assert abs(got["loudness"] - ref["loudness"]) <= LU_TOL
-        # far tighter in practice: only summation order differs
-        assert abs(got["loudness"] - ref["loudness"]) <= 1e-6
+        # far tighter in practice (10 log10(1 + rtol) = 4.35 rtol)
+        assert abs(got["loudness"] - ref["loudness"]) <= max(1e-6, 4.5 * rtol)
         np.testing.assert_allclose(got["sum_abs"], ref["sum_abs"], rtol=rtol)
         np.testing.assert_allclose(got["sum_rel"], ref["sum_rel"], rtol=rtol)
     assert abs(got["lra"] - ref["lra"]) <= LU_TOL

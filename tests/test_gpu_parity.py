@@ -385,7 +385,7 @@ def test_full_size_properties():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("seed", range(11, 11 + int(os.environ.get("LGD_FUZZ_SEEDS", "8"))))
 def test_fuzz_mixed_plans(scanner, oracle, seed):
     """Random plans: 12 tracks each with random rate, layout, length (from a few frames to
     ~25 s, clustered around the block-length edges 100 ms / 400 ms / 3 s), gain and content
@@ -420,13 +420,14 @@ def test_fuzz_mixed_plans(scanner, oracle, seed):
                                  [s[0] for s in specs], true_peak=tp, album=True)
     refs = [oracle.scan_track(p, s[0]) for p, s in zip(pcms, specs)]
     for got, ref, s in zip(tracks, refs, specs):
-        check_track(got, ref, tp=tp, rate=s[0])
+        check_track(got, ref, tp=tp, rate=s[0], lf_tones=True)
     states = [r["state"] for r in refs]
     det = oracle.gating_detail(states)
     assert album["n_abs"] == det["n_abs"] and album["n_rel"] == det["n_rel"]
     want = oracle.album_loudness(states)
-    assert album["loudness"] == want or abs(album["loudness"] - want) <= 1e-6
-    assert abs(album["lra"] - oracle.album_lra(states)) <= 1e-6
+    # (tones of tens of Hz at 176 / 192 kHz: see gpu_util.energy_rtol; the bar is 0.01 LU)
+    assert album["loudness"] == want or abs(album["loudness"] - want) <= 2e-5
+    assert abs(album["lra"] - oracle.album_lra(states)) <= 2e-5
 
 
 def torch_empty(ch):

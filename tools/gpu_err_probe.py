@@ -1,4 +1,6 @@
-"""Probe: GPU sub-block energies vs a long-double DF-II reference."""
+"""Probe: GPU sub-block energies, and the oracle's (= libebur128's double DF-II) 400 ms
+block energies, against a long-double evaluation of the same filter.
+    gpu_err_probe.py [rate] [noise|step|tone]"""
 import sys, os, math
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import numpy as np, torch
@@ -21,6 +23,8 @@ rng = np.random.default_rng(0)
 t = np.arange(N) / fs
 if kind == "noise":
     x = rng.standard_normal(N) * 0.1
+elif kind == "tone":
+    x = 0.7 * np.sin(2 * np.pi * 37.0 * t)
 else:
     x = rng.standard_normal(N) * 0.1 * np.where(t < 2, 1.0, 1e-4) + np.where(t < 2, 0.9*np.sin(2*np.pi*30*t), 0)
 x = (np.clip(np.round(x * 32768), -32768, 32767) / 32768).astype(np.float32)
@@ -30,6 +34,10 @@ s100 = (fs + 5) // 10
 nsb = N // s100
 Eld = np.array([float((y[k*s100:(k+1)*s100]**2).sum()) for k in range(nsb)])
 st = o.State(1, fs).add(x.reshape(-1, 1))
+Zld = (Eld[:-3] + Eld[1:-2] + Eld[2:-1] + Eld[3:]) / (4.0 * s100)
+Zo = st.gating_blocks()
+if len(Zo) == len(Zld):
+    print("fs", fs, kind, "ORACLE (double DF-II) vs long double, 400 ms blocks: max rel", (np.abs(Zo - Zld) / Zld).max())
 for seg in (1000000, 3):
     for chunk in (0, 25, 75):
         s = DeviceScanner(0)
