@@ -387,18 +387,19 @@ def test_full_size_properties():
 
 @pytest.mark.parametrize("seed", range(11, 11 + int(os.environ.get("LGD_FUZZ_SEEDS", "8"))))
 def test_fuzz_mixed_plans(scanner, oracle, seed):
-    """Random plans: 12 tracks each with random rate, layout, length (from a few frames to
-    ~25 s, clustered around the block-length edges 100 ms / 400 ms / 3 s), gain and content
-    (noise, LF tone, impulses, silence), true peak on or off, one album per plan."""
+    """Random plans: 12 tracks each with random rate, layout (1..8 channels, now and then a
+    wide stream), length (from a few frames to ~25 s, clustered around the block-length
+    edges 100 ms / 400 ms / 3 s), gain and content (noise, LF tone, impulses, silence),
+    true peak on or off, cut into a random number of albums (some empty)."""
     rng = np.random.default_rng(seed)
     rates = [8000, 11025, 22050, 32000, 44100, 48000, 88200, 96000, 176400, 192000]
     specs, pcms = [], []
     for i in range(12):
         rate = rates[int(rng.integers(len(rates)))]
-        ch = int(rng.choice([1, 2, 2, 2, 3, 5, 6, 8]))
+        ch = int(rng.choice([1, 2, 2, 2, 3, 5, 6, 8, 2, 2, 12, 17, 33]))
         edge = float(rng.choice([0.0, 0.1, 0.4, 3.0, 3.1]))
         secs = edge + float(rng.choice([0.0, 1.0 / rate, 0.003, 0.0999, 0.1001, 0.37, 1.234, 7.7, 25.0])) \
-            * (0.3 if rate > 96000 or ch > 2 else 1.0)
+            * (0.3 if rate > 96000 or ch > 2 else 1.0) * (0.3 if ch > 8 else 1.0)
         frames = max(0, int(round(secs * rate)))
         kind = int(rng.integers(4))
         t = np.arange(frames)[:, None] / rate
@@ -416,18 +417,28 @@ def test_fuzz_mixed_plans(scanner, oracle, seed):
         pcms.append(synth.snap_s16_numpy(x.astype(np.float32).reshape(frames, ch)))
         specs.append((rate, ch, frames))
     tp = bool(rng.integers(2))
-    tracks, album = scanner.scan([to_dev(p) if p.size else torch_empty(p.shape[1]) for p in pcms],
-                                 [s[0] for s in specs], true_peak=tp, album=True)
+    n_albums = int(rng.integers(1, 6))
+    albums = sorted(int(a) for a in rng.integers(0, n_albums, size=12))
+    albums[-1] = max(albums[-1], n_albums - 1) if rng.integers(2) else albums[-1]   # sometimes trailing empties
+    tracks, res = scanner.scan([to_dev(p) if p.size else torch_empty(p.shape[1]) for p in pcms],
+                               [s[0] for s in specs], true_peak=tp, albums=albums)
     refs = [oracle.scan_track(p, s[0]) for p, s in zip(pcms, specs)]
     for got, ref, s in zip(tracks, refs, specs):
         check_track(got, ref, tp=tp, rate=s[0], lf_tones=True)
-    states = [r["state"] for r in refs]
-    det = oracle.gating_detail(states)
-    assert album["n_abs"] == det["n_abs"] and album["n_rel"] == det["n_rel"]
-    want = oracle.album_loudness(states)
-    # (tones of tens of Hz at 176 / 192 kHz: see gpu_util.energy_rtol; the bar is 0.01 LU)
-    assert album["loudness"] == want or abs(album["loudness"] - want) <= 2e-5
-    assert abs(album["lra"] - oracle.album_lra(states)) <= 2e-5
+    assert len(res) == max(albums) + 1
+    for a, album in enumerate(res):
+        states = [r["state"] for r, al in zip(refs, albums) if al == a]
+        if not states:
+            assert album["n_abs"] == 0 and album["loudness"] == -np.inf and album["lra"] == 0.0
+            continue
+        det = oracle.gating_detail(states)
+        assert album["n_abs"] == det["n_abs"] and album["n_rel"] == det["n_rel"]
+        want = oracle.album_loudness(states)
+        # (tones of tens of Hz at 176 / 192 kHz: see gpu_util.energy_rtol; the bar is 0.01 LU)
+        assert album["loudness"] == want or abs(album["loudness"] - want) <= 2e-5
+        assert abs(album["lra"] - oracle.album_lra(states)) <= 2e-5
+        if tp:
+            assert abs(album["peak"] - max(r["peak"] for r, al in zip(refs, albums) if al == a)) <= 1e-4
 
 
 def torch_empty(ch):
