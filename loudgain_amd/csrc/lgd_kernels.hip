@@ -839,7 +839,8 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
 }
 
 // chunk lengths compiled in; the host picks one that divides the rate's s100
-extern "C" const int lgd_chunk_table[] = {25, 35, 40, 42, 45, 48, 49, 50, 60, 63, 70, 75, 0};
+// (40, 42, 48, 60, 70 were tried and dropped: their unroll factors spill registers)
+extern "C" const int lgd_chunk_table[] = {25, 35, 45, 49, 50, 63, 75, 0};
 
 
 // F: DEVICE pointer to the group's constants
@@ -857,11 +858,6 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, c
   switch (chunk) {
     case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, F, s);
     case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, F, s);
-    case 40: return launch_scan_c<40>(nch, tp, segs, n_seg, F, s);
-    case 42: return launch_scan_c<42>(nch, tp, segs, n_seg, F, s);
-    case 48: return launch_scan_c<48>(nch, tp, segs, n_seg, F, s);
-    case 60: return launch_scan_c<60>(nch, tp, segs, n_seg, F, s);
-    case 70: return launch_scan_c<70>(nch, tp, segs, n_seg, F, s);
     case 45: return launch_scan_c<45>(nch, tp, segs, n_seg, F, s);
     case 49: return launch_scan_c<49>(nch, tp, segs, n_seg, F, s);
     case 50: return launch_scan_c<50>(nch, tp, segs, n_seg, F, s);
