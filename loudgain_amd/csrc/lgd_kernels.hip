@@ -98,7 +98,7 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // TP  0 = no interpolator (>= 192 kHz or disabled), 4 = 4x, 2 = 2x
 // LDS layout of a staged tile.
 //  G == 0 (run-time channel count): interleaved as in memory, frame stride nch.
-//  G == 1, 2: PLANAR, one plane per channel, and every lane's C-frame chunk is
+//  G >= 1 (compiled for 1, 2 and 6 = 5.1): PLANAR, one plane per channel, and every lane's C-frame chunk is
 //  followed by PAD unused floats so that the lane stride C + PAD is odd: 64 lanes
 //  reading the same chunk position then hit 32 different banks (an even stride,
 //  e.g. interleaved stereo, costs 2..32-way ds_read conflicts).
@@ -106,7 +106,11 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 //     PO + f + floor(f / C) * PAD,   PO = HALO + PAD + (run-time alignment shift)
 template <int C, int G>
 struct LdsLayout {
-  static constexpr bool PLANAR = (G == 1) || (G == 2);
+  static constexpr bool PLANAR = (G >= 1);
+  // the 16-B alignment shift of a tile (0..3 floats) is a whole number of frames for
+  // 1, 2 (and 4) channels; otherwise (5.1: G = 6) the planes are addressed one frame
+  // further in and the channel of a staged float is (index - shift) mod G
+  static constexpr bool SHIFT_WHOLE = (G == 0) || (4 % (G ? G : 1) == 0);
   static constexpr int PAD = (PLANAR && (C % 2 == 0)) ? 1 : 0;
   static constexpr int STRIDE = C + PAD;  // lane stride inside a plane
 };
@@ -138,7 +142,7 @@ struct ScanCfg {
 template <int C, int G, int TP, bool WIDE = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
                                                       G ? LGD_WAVE * G : (WIDE ? 1024 : 512)),
-                          amdgpu_waves_per_eu(G ? 2 : (WIDE ? 4 : 2), (G && TP) ? 2 : 4))) void lgd_scan_kernel(
+                          amdgpu_waves_per_eu(G ? (G > 2 ? 3 : 2) : (WIDE ? 4 : 2), (G && G <= 2 && TP) ? 2 : 4))) void lgd_scan_kernel(
     const LgdSeg *__restrict__ segs, const LgdFilt *__restrict__ Fg, const int nch_rt) {
   using K = ScanCfg<C, TP>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -159,7 +163,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   const int shift = (G == 0 && sg.nch_total != (G ? G : nch_rt)) ? 0 : (int)((sg.f0 * nch) & 3);
   const long long n_frames = sg.n_floats / (G ? G : sg.nch_total);
   const int nvec = ((K::TILE_F + K::HALO) * nch + 4) >> 2;  // 16-B vectors per tile
+  // frame slot of tile frame -HALO inside a plane
   using LL = LdsLayout<C, G>;
+  const int slot_shift = LL::SHIFT_WHOLE ? shift / (G ? G : 1) : 1;
   // vector i of a thread is in range for EVERY thread when this holds (compile-time
   // for the fixed-channel-count kernels: no exec masking around full vectors)
 #define LGD_VEC_ALWAYS(i_) (G != 0 && (LGD_WAVE * G) * ((i_) + 1) <= (((K::TILE_F + K::HALO) * G + 4) >> 2))
@@ -258,10 +264,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         lgd_lds_write2(lds + PLANE + jj_, (v_).y, (v_).w);                               \
       } else {                                                                           \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                               \
-          const int i_ = 4 * (idx_) + e_;                                                \
+          const int i_ = LL::SHIFT_WHOLE ? 4 * (idx_) + e_ : 4 * (idx_) + e_ - shift + G; \
           const int c_ = i_ % G, jj_ = i_ / G;                                           \
           /* f + C >= 0 always (HALO <= C): floor(f / C) = (f + C) / C - 1 */            \
-          const int fpc_ = jj_ - K::HALO - shift / G + C;                                \
+          const int fpc_ = jj_ - K::HALO - slot_shift + C;                               \
           lds[c_ * PLANE + jj_ + LL::PAD * (int)((unsigned)fpc_ / (unsigned)C)] = (v_)[e_]; \
         }                                                                                \
       }                                                                                  \
@@ -311,7 +317,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     constexpr int HX = K::HX;
     // this lane's chunk; LGD_X(j) = frame j of it (j < 0: history in the previous chunk)
     const float *chunk = LL::PLANAR
-        ? lds + ch * PLANE + (K::HALO + shift / (G ? G : 1)) + lane * LL::STRIDE  // + PAD folded below
+        ? lds + ch * PLANE + (K::HALO + slot_shift) + lane * LL::STRIDE  // + PAD folded below
         : lds + shift + (K::HALO + lane * C) * nch + ch;
 #define LGD_X(j) (LL::PLANAR ? chunk[(j) + ((j) < 0 ? 0 : LL::PAD)] : chunk[(j) * (G ? G : nch)])
 
@@ -791,7 +797,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 // LdsLayout / PLANE in the kernel.  generic != 0: the run-time-channel-count kernel.
 extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
   const int halo = tp == 2 ? 24 : 12;
-  const bool planar = !generic && nch <= 2;
+  const bool planar = !generic && (nch <= 2 || nch == 6);
   if (planar) {
     const int pad = (chunk % 2 == 0) ? 1 : 0;
     const int plane = (halo + 4 + pad + LGD_WAVE * (chunk + pad) + 4 + 8 + 1) & ~1;
@@ -833,6 +839,15 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
     if (tp == 2) return launch_scan_t<C, 1, 2>(segs, n_seg, F, nch, s);
     return launch_scan_t<C, 1, 0>(segs, n_seg, F, nch, s);
   }
+  if (nch == 6) {  // 5.1: the short chunks only (six planes per workgroup)
+    if constexpr (C == 25 || C == 35) {
+      if (tp == 4) return launch_scan_t<C, 6, 4>(segs, n_seg, F, nch, s);
+      if (tp == 2) return launch_scan_t<C, 6, 2>(segs, n_seg, F, nch, s);
+      return launch_scan_t<C, 6, 0>(segs, n_seg, F, nch, s);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (tp == 4) return launch_scan_t<C, 2, 4>(segs, n_seg, F, nch, s);
   if (tp == 2) return launch_scan_t<C, 2, 2>(segs, n_seg, F, nch, s);
   return launch_scan_t<C, 2, 0>(segs, n_seg, F, nch, s);
@@ -854,7 +869,7 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, c
     if (tp == 2) return launch_scan_generic<2>(nch, segs, n_seg, F, s);
     return launch_scan_generic<0>(nch, segs, n_seg, F, s);
   }
-  if (nch > 2) return hipErrorInvalidValue;
+  if (nch > 2 && nch != 6) return hipErrorInvalidValue;
   switch (chunk) {
     case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, F, s);
     case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, F, s);
