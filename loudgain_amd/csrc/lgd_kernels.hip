@@ -38,6 +38,23 @@
 
 #define LGD_WAVE 64
 
+// Wave priorities per section of a tile (measured, tools/prio_sweep.sh): the latency-bound
+// sections (staging, wave scan) first, and phase C above phase A -- the wave closer to
+// the end of its tile wins the SIMD, so its workgroup reaches the next barrier (and issues
+// the next tile's loads) sooner.  Equal priorities for A and C cost 3-5 %; an extra
+// asymmetry by hardware wave slot gained nothing.
+#ifndef LGD_PRIO_STAGE
+#define LGD_PRIO_STAGE 3
+#endif
+#ifndef LGD_PRIO_SCAN
+#define LGD_PRIO_SCAN 3
+#endif
+#ifndef LGD_PRIO_A
+#define LGD_PRIO_A 1
+#endif
+#ifndef LGD_PRIO_C
+#define LGD_PRIO_C 2
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Pointers that arrive inside a descriptor in memory lose their address space and
@@ -245,7 +262,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 
   for (int k = -sg.n_warm_tiles; k < n_main; ++k) {
     const long long tb = sg.f0 + (long long)k * K::TILE_F;  // first frame of the tile
-    __builtin_amdgcn_s_setprio(2);  // staging: get the stores, the barrier and the next loads out first
+    __builtin_amdgcn_s_setprio(LGD_PRIO_STAGE);  // staging: get the stores, the barrier and the next loads out first
     __syncthreads();  // every wave is done reading the previous tile
     // LDS slot of frame f of a plane (planar layouts): PO_W + f + floor(f / C) * PAD,
     // written in terms of the vector's own frame slot jj = f + HALO + shift / G
@@ -309,7 +326,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 #undef LGD_STORE_VEC
     __syncthreads();
     if (k + 1 < n_main) LGD_PREFETCH(k + 1); else pf_valid = false;
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(LGD_PRIO_A);
 
     // this lane's chunk of this wave's channel: frames [tb + lane*C, +C), frame
     // stride nch floats, streamed from LDS U frames at a time
@@ -447,7 +464,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 
       // (latency-bound section: issue priority over the SIMD's other wave, which is most
       // likely streaming through phase A or C)
-      __builtin_amdgcn_s_setprio(2);
+      __builtin_amdgcn_s_setprio(LGD_PRIO_SCAN);
       // ---- B: inject the carry at lane 0, then Kogge-Stone over 64 lanes.  The
       // transition is block lower triangular: rows 0,1 see columns 0,1 only. ----
       if (lane == 0) {
@@ -517,7 +534,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         ps[h][0] = sv[h][2] * dcg;
         ps[h][1] = sv[h][3] * dcg;
       }
-      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(LGD_PRIO_C);
     }
 
     if (k < 0) continue;  // warm-up tile: only the carry matters
