@@ -444,3 +444,35 @@ def test_fuzz_mixed_plans(scanner, oracle, seed):
 def torch_empty(ch):
     import torch
     return torch.zeros((0, ch), dtype=torch.float32, device="cuda")
+
+
+def test_large_album_range_selection(scanner):
+    """The album's loudness range is an exact order statistic over ALL listed 3 s blocks
+    (tens of thousands here: far more than the LRA kernel stages at once).  40 ten-minute
+    tracks = one base track at 40 power-of-two-free gains; expected values from numpy over the
+    100 ms energies of each scanned track."""
+    import torch
+    from loudgain_amd.album import album_from_partials
+    rate = 48000
+    base = synth.track_torch(10 * 60 * rate, 2, rate, seed=404, step_s=7.0, device="cuda")
+    gains = [0.25 + 0.018 * i for i in range(40)]
+    pcms = [base * g for g in gains]
+    tracks, album = scanner.scan(pcms, rate, true_peak=False, album=True)
+    st_all, zsum, zn, z_all = [], 0.0, 0, []
+    for i in range(len(pcms)):
+        e = scanner.subblock_energies(i)
+        z = (e[:-3] + e[1:-2] + e[2:-1] + e[3:]) / (4.0 * 4800)
+        z_all.append(z[z >= ABS_GATE])
+        k = np.arange((len(e) - 30) // 10 + 1)
+        st = np.array([e[10 * j:10 * j + 30].sum() for j in k]) / (30.0 * 4800)
+        st_all.append(st[st >= ABS_GATE])
+    z_all = np.concatenate(z_all)
+    thr = 0.1 * z_all.sum() / len(z_all)
+    sel = z_all[z_all >= thr]
+    want = album_from_partials(sel.sum(), len(sel), np.concatenate(st_all), max(t["peak"] for t in tracks))
+    assert album["n_st"] == sum(len(s) for s in st_all) > 15000
+    assert album["n_abs"] == len(z_all) and album["n_rel"] == len(sel)
+    assert abs(album["loudness"] - want["loudness"]) <= 1e-9
+    assert abs(album["lra"] - want["lra"]) <= 1e-9
+    del pcms, base
+    torch.cuda.empty_cache()
