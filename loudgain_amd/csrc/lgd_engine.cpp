@@ -360,8 +360,8 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   const size_t lds_cap = 160 * 1024;  // per CU == per workgroup limit on gfx950
   if (forced) {
     for (const int *p = lgd_chunk_table; *p; ++p)
-      if (*p == forced && s100 % *p == 0 && (nch != 6 || *p == 25 || *p == 35) &&
-          lgd_scan_lds_bytes(*p, (int)nch, tp, nch > 2 && nch != 6) <= lds_cap)
+      if (*p == forced && s100 % *p == 0 && (nch <= 2 || *p == 25 || *p == 35) &&
+          lgd_scan_lds_bytes(*p, (int)nch, tp, nch > 2 && !(nch == 3 || nch == 4 || nch == 6 || nch == 8)) <= lds_cap)
         return *p;
     return 0;
   }
@@ -371,14 +371,15 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   // the run-time-channel-count kernel is compiled for 16 waves (<= 128 VGPRs):
   // short chunks keep its prefetch registers within that
   static const int pref_many[] = {25, 35, 45, 49, 50, 63, 75, 0};
-  // 5.1 (six planes per workgroup): the two short chunks compiled for it, two workgroups per CU
+  // 3, 4, 6 (5.1), 8 (7.1) planes per workgroup: the two short chunks compiled for them
   static const int pref_51[] = {35, 25, 0};
-  const int *pref = nch <= 2 ? pref_fast : (nch == 6 ? pref_51 : pref_many);
-  const bool generic = nch > 2 && nch != 6;
+  const bool multi = nch == 3 || nch == 4 || nch == 6 || nch == 8;  // planar specialisations exist
+  const int *pref = nch <= 2 ? pref_fast : (multi ? pref_51 : pref_many);
+  const bool generic = nch > 2 && !multi;
   for (int pass = 0; pass < 2; ++pass)
     for (const int *p = pref; *p; ++p)
       if (s100 % *p == 0 &&
-          lgd_scan_lds_bytes(*p, (int)nch, tp, generic) <= (pass ? lds_cap : (nch == 6 ? lds_cap / 2 : lds_cap / 4)))
+          lgd_scan_lds_bytes(*p, (int)nch, tp, generic) <= (pass ? lds_cap : (multi ? lds_cap / 2 : lds_cap / 4)))
         return *p;
   return 0;
 }
@@ -498,7 +499,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         g.nch = g_nch;
         g.nch_total = tr.channels;
         g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
-        g.chunk = ((g_nch <= 2 || g_nch == 6) && g_nch == tr.channels)
+        g.chunk = ((g_nch <= 4 || g_nch == 6 || g_nch == 8) && g_nch == tr.channels)
                       ? pick_chunk(c->p_chunk, s100, g_nch, g.tp) : 0;
         // fast kernels: mono / stereo with a chunk that divides the sub-block; anything else
         // (more channels, channel groups, rates such as 11 025 Hz) goes to the generic kernel,
