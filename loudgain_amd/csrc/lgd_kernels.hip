@@ -14,8 +14,11 @@
 //   B. a 6-step wave scan of the affine maps  s -> A^C s + z  turns the z_lane
 //      into the exact filter state at the start of every lane's chunk,
 //   C. re-runs its C frames from that state, now producing y, y^2 and peaks.
+// In A and C a lane's chunk runs as two half-chunks whose recurrences are issued
+// interleaved (ILP at two waves per SIMD); the sections of a tile run at different wave
+// priorities (LGD_PRIO_*).
 // The state that enters a segment comes from `n_warm_tiles` tiles of A+B only
-// over the audio just before it (the filter's memory is < 1e-26 after 300 ms).
+// over the audio just before it (default 200 ms: the filter's memory is < 1e-17 by then).
 //
 // Conditioning: libebur128 runs the merged 4th-order filter in direct form II,
 // whose state v = x/A(z) is ~1e5 x the signal for low-frequency content and
