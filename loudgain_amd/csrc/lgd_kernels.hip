@@ -567,6 +567,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     // starting at chunk frame jb: U x NPH independent accumulation chains, tap-major,
     // so that neighbouring instructions never depend on each other and share the
     // coefficient SGPR
+    // fold U interpolated magnitudes into the running peak; only the tile that holds the
+    // end of the track masks outputs past the last input frame (block-uniform branch, so
+    // the other tiles pay no per-sample compare + select)
+#define LGD_TP_FOLD(m_, jb)                                                             \
+    do {                                                                                \
+      if (__builtin_expect(tail, 0)) {                                                  \
+        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                                \
+          pk_t = fmaxf(pk_t, ((jb) + u_ < nvalid) ? (m_)[u_] : 0.f);                    \
+        asm volatile("" ::: "memory"); /* keep this a branch, not selects */            \
+      } else {                                                                          \
+        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) pk_t = fmaxf(pk_t, (m_)[u_]);  \
+      }                                                                                 \
+    } while (0)
 #define LGD_PEAKS_BLOCK(wv, jb)                                                         \
     do {                                                                                \
       _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) pk_s = fmaxf(pk_s, fabsf(wv[HX + u_])); \
@@ -588,10 +601,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
             o2_[u_] = fmaf(c2_, ab_.x, o2_[u_]);                                        \
           }                                                                             \
         }                                                                               \
-        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                              \
-          float m_ = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));        \
-          if (tail) m_ = ((jb) + u_ < nvalid) ? m_ : 0.f;                               \
-          pk_t = fmaxf(pk_t, m_);                                                       \
+        if constexpr (G == 0 || G > 2) { /* register-tight variants: fold as they come */ \
+          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                            \
+            float m_ = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));      \
+            if (tail) m_ = ((jb) + u_ < nvalid) ? m_ : 0.f;                             \
+            pk_t = fmaxf(pk_t, m_);                                                     \
+          }                                                                             \
+        } else {                                                                        \
+          float m_[U];                                                                  \
+          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                              \
+            m_[u_] = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));        \
+          LGD_TP_FOLD(m_, jb);                                                          \
         }                                                                               \
       } else if constexpr (TP == 2) {                                                   \
         /* the one non-trivial 2x phase is symmetric: 12 sums + 12 FMAs per sample */   \
@@ -602,10 +622,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                              \
             o1_[u_] = fmaf(c1_, wv[HX + u_ - k_] + wv[u_ + k_], o1_[u_]);               \
         }                                                                               \
-        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                              \
-          float m_ = fabsf(o1_[u_]);                                                    \
-          if (tail) m_ = ((jb) + u_ < nvalid) ? m_ : 0.f;                               \
-          pk_t = fmaxf(pk_t, m_);                                                       \
+        if constexpr (G == 0 || G > 2) {                                                \
+          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                            \
+            float m_ = fabsf(o1_[u_]);                                                  \
+            if (tail) m_ = ((jb) + u_ < nvalid) ? m_ : 0.f;                             \
+            pk_t = fmaxf(pk_t, m_);                                                     \
+          }                                                                             \
+        } else {                                                                        \
+          float m_[U];                                                                  \
+          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) m_[u_] = fabsf(o1_[u_]);     \
+          LGD_TP_FOLD(m_, jb);                                                          \
         }                                                                               \
       }                                                                                 \
     } while (0)
@@ -761,6 +787,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       }
     }
 #undef LGD_PEAKS_BLOCK
+#undef LGD_TP_FOLD
 #undef LGD_X
 
     // ---- 100 ms sub-block sums: deterministic per-lane accumulate + wave tree
