@@ -348,7 +348,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     if (dbg & 2) continue;
     // start states of the two sub-chunks, as (q1, q2) and (p1, p2)
     double qs[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, ps[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    constexpr int H1 = K::H1, H2 = K::H2;
+    // planar multi-channel variants (3+ waves per SIMD, register-tight): one stream per lane
+    constexpr int H1 = (G > 2) ? C : K::H1, H2 = C - H1;
     if (filt) {
       // ---- A: zero-state runs of q' = x/ra, p' = q'/pa over both sub-chunks (4 FMAs
       // per sample and stream, the two streams interleaved).  (1 - z^-1)^2 commutes
@@ -421,7 +422,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
             xa[1][u] = xn[1][u];
           }
         }
-#pragma unroll 1
+#pragma unroll (H2 == 0 ? C / U : 1)
         for (int j0 = a_end2; j0 < a_end1; j0 += U) {  // the longer first sub-chunk alone
           float xn[U];
 #pragma unroll
@@ -754,7 +755,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           }
         }
       }
-#pragma unroll 1
+#pragma unroll (H2 == 0 ? C / U : 1)
       for (int j0 = c_end2; j0 < c_end1; j0 += U) {  // the longer first sub-chunk alone
         float xn[U];
         if constexpr (PIPE) {
@@ -888,7 +889,7 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
   }
   if (nch > 2) {  // 3, 4, 6 or 8 planes per workgroup (2.1, quad, 5.1, 7.1): the short chunks only
                   // (5 planes measured slower than the run-time-channel kernel: not compiled)
-    if constexpr (C == 25 || C == 35) {
+    if constexpr (C == 25 || C == 35) {  // (45 / 50 spill 50+ registers with the interpolator)
 #define LGD_DISPATCH_G(g_)                                                              \
       if (nch == g_) {                                                                  \
         if (tp == 4) return launch_scan_t<C, g_, 4>(segs, n_seg, F, nch, s);            \
