@@ -123,7 +123,7 @@ static void design_scan_basis(LgdFilt &F, int chunk, bool one_stream) {
   mat4_mul(T, Ac, M);
   mat4_mul(M, Ti, M);
   const ld TB[4] = {1, alr, gar, 0};  // T * (1, 0, 1, 0)
-  // (the planar 3/4/6/8-channel kernels run one stream per lane: second half-chunk empty)
+  // (the fixed-channel kernels run one stream per lane: second half-chunk empty)
   const int H1 = one_stream ? chunk : lgd_h1(chunk), H2 = chunk - H1;
   // powers of M up to the chunk length; pick off what the kernel needs
   for (int i = 0; i <= chunk; ++i) {
@@ -513,7 +513,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
           return fail(LGD_EUNSUP, "track %u: sample rate %u Hz is below the 4 kHz floor", t, tr.rate);
         memset(&g.F, 0, sizeof(g.F));
         design_kfilter((double)g.rate, g.F.pb, g.F.pa, g.F.ra);
-        design_scan_basis(g.F, g.chunk, !g.generic && g_nch > 2);
+        design_scan_basis(g.F, g.chunk, !g.generic);
         design_interp(g.tp, g.F.tp);
         g.F.pbn[0] = g.F.pb[1] / g.F.pb[0];
         g.F.pbn[1] = g.F.pb[2] / g.F.pb[0];

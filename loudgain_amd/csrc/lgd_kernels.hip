@@ -348,8 +348,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     if (dbg & 2) continue;
     // start states of the two sub-chunks, as (q1, q2) and (p1, p2)
     double qs[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, ps[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    // planar multi-channel variants (3+ waves per SIMD, register-tight): one stream per lane
-    constexpr int H1 = (G > 2) ? C : K::H1, H2 = C - H1;
+    // The fixed-channel variants run ONE stream per lane (H2 = 0: the two-stream loops below
+    // fold away).  Two interleaved half-chunks were worth 8 % while both waves of a SIMD
+    // competed at equal priority; with the phase priorities (LGD_PRIO_*) the other wave
+    // hides the dependency latency and the split only costs its combine steps (measured:
+    // one stream -2 % at 48 kHz, -5 % at 44.1 kHz, -10 % at 22.05 kHz).  The
+    // run-time-channel kernel keeps two streams.
+    constexpr int H1 = (G != 0) ? C : K::H1, H2 = C - H1;
     if (filt) {
       // ---- A: zero-state runs of q' = x/ra, p' = q'/pa over both sub-chunks (4 FMAs
       // per sample and stream, the two streams interleaved).  (1 - z^-1)^2 commutes

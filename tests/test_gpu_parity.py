@@ -351,7 +351,8 @@ def test_full_size_properties():
     ref = lgoracle.scan_track(head, rate)
     (hd,), _ = sc.scan([pcm[: 90 * rate]], rate, true_peak=True)
     check_track(hd, ref)
-    np.testing.assert_array_equal(sc.subblock_energies(0), e_ref[:900])   # causal: prefix energies identical
+    # causal: the prefix has the same energies (another segmentation: equal to rounding)
+    np.testing.assert_allclose(sc.subblock_energies(0), e_ref[:900], rtol=1e-12, atol=0)
     # exact scaling
     half = pcm * 0.5
     (hf,), _ = sc.scan([half], rate, true_peak=True)
