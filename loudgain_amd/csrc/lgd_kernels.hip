@@ -14,9 +14,9 @@
 //   B. a 6-step wave scan of the affine maps  s -> A^C s + z  turns the z_lane
 //      into the exact filter state at the start of every lane's chunk,
 //   C. re-runs its C frames from that state, now producing y, y^2 and peaks.
-// In A and C a lane's chunk runs as two half-chunks whose recurrences are issued
-// interleaved (ILP at two waves per SIMD); the sections of a tile run at different wave
-// priorities (LGD_PRIO_*).
+// The sections of a tile run at different wave priorities (LGD_PRIO_*): the SIMD's other
+// wave hides the latency of the fp64 dependency chains.  (The run-time-channel kernel
+// additionally splits a lane's chunk into two half-chunks issued interleaved.)
 // The state that enters a segment comes from `n_warm_tiles` tiles of A+B only
 // over the audio just before it (default 200 ms: the filter's memory is < 1e-17 by then).
 //
