@@ -106,7 +106,7 @@ static void mat4_mul(const ld *X, const ld *Y, ld *Z) {
 // i.e. s <- Ac s + Bc w.  With T = [[1,0,0,0],[al,-al*be,0,0],[0,0,ga,0],[0,0,0,ga]]
 // the kernels carry T s; M = T Ac T^-1 is well conditioned (all powers <= ~10),
 // so its powers are formed by plain repeated multiplication in long double.
-static void design_scan_basis(LgdFilt &F, int chunk, bool one_stream) {
+static void design_scan_basis(LgdFilt &F, int chunk) {
   const ld ra1 = F.ra[0], ra2 = F.ra[1], pa1 = F.pa[0], pa2 = F.pa[1];
   const ld r = sqrtl(ra2);                 // radius of the (nearly double) RLB pole
   const ld al = 1.0L / (1.0L - r), be = r;
@@ -123,24 +123,14 @@ static void design_scan_basis(LgdFilt &F, int chunk, bool one_stream) {
   mat4_mul(T, Ac, M);
   mat4_mul(M, Ti, M);
   const ld TB[4] = {1, alr, gar, 0};  // T * (1, 0, 1, 0)
-  // (the fixed-channel kernels run one stream per lane: second half-chunk empty)
-  const int H1 = one_stream ? chunk : lgd_h1(chunk), H2 = chunk - H1;
-  // powers of M up to the chunk length; pick off what the kernel needs
+  // powers of M up to the chunk length; pick off what the kernel needs:
+  // gC[0] = M^(C-1) T Bc, gC[1] = M^(C-2) T Bc (Mk == M^i in the loop)
   for (int i = 0; i <= chunk; ++i) {
-    // Mk == M^i here.  A sub-chunk of length H: g[0] = M^(H-1) T Bc, g[1] = M^(H-2) T Bc
-    for (int which = 0; which < 2; ++which) {
-      const int H = which ? H2 : H1;
-      double (*g)[4] = which ? F.gH2 : F.gH1;
-      if (i == H - 1 || i == H - 2) {
-        for (int rr = 0; rr < 4; ++rr) {
-          ld acc = 0;
-          for (int c = 0; c < 4; ++c) acc += Mk[4 * rr + c] * TB[c];
-          g[i == H - 1 ? 0 : 1][rr] = (double)acc;
-        }
-      }
-      if (i == H) {
-        double *dst = which ? F.MH2 : F.MH1;
-        for (int e = 0; e < 16; ++e) dst[e] = (double)Mk[e];
+    if (i == chunk - 1 || i == chunk - 2) {
+      for (int rr = 0; rr < 4; ++rr) {
+        ld acc = 0;
+        for (int c = 0; c < 4; ++c) acc += Mk[4 * rr + c] * TB[c];
+        F.gC[i == chunk - 1 ? 0 : 1][rr] = (double)acc;
       }
     }
     if (i < chunk) mat4_mul(M, Mk, Mk);
@@ -513,7 +503,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
           return fail(LGD_EUNSUP, "track %u: sample rate %u Hz is below the 4 kHz floor", t, tr.rate);
         memset(&g.F, 0, sizeof(g.F));
         design_kfilter((double)g.rate, g.F.pb, g.F.pa, g.F.ra);
-        design_scan_basis(g.F, g.chunk, !g.generic);
+        design_scan_basis(g.F, g.chunk);
         design_interp(g.tp, g.F.tp);
         g.F.pbn[0] = g.F.pb[1] / g.F.pb[0];
         g.F.pbn[1] = g.F.pb[2] / g.F.pb[0];

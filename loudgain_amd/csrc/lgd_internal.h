@@ -33,11 +33,7 @@ struct LgdFilt {
   double pb0sq;      // ... and scales each 100 ms sum by pb0^2
   double alpha, beta, inv_alpha, inv_beta;  // slope coordinate of the RLB pole pair
   double gamma, dc;  // shelf-state scaling (dc = 1 / (1 + pa1 + pa2))
-  double gH1[2][4];  // effect of w[0], w[1] of the first sub-chunk (H1 frames) on its end
-                     // state, scan basis; gH2: the same for the second (C - H1 frames)
-  double gH2[2][4];
-  double MH1[16];    // transition over H1 / over C - H1 frames (scan basis, row-major)
-  double MH2[16];
+  double gC[2][4];   // effect of w[0], w[1] of a chunk (C frames) on its end state, scan basis
   double P[6][16];   // transition over C * 2^j frames, j = 0..5 (scan basis, row-major;
                      // block lower triangular: P[.][2], [3], [6], [7] are zero)
   float tp[36];      // 4x: phases 1..3 x 12 taps; 2x: phase 1 x 24 taps (A.5)
@@ -52,10 +48,6 @@ constexpr int lgd_unroll(int C) {
   return (C % 8 == 0) ? 8 : (C % 7 == 0) ? 7 : (C % 6 == 0) ? 6 : (C % 5 == 0) ? 5
        : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : (C % 2 == 0) ? 2 : 1;
 }
-// length of the first of the two sub-chunks a lane's chunk is cut into (a
-// multiple of the step, at least half of C)
-constexpr int lgd_h1(int C) { return lgd_unroll(C) * (((C / lgd_unroll(C)) + 1) / 2); }
-
 // The gating epilogue walks the 400 ms blocks of a track in slices of this many
 // blocks, one workgroup per slice (fixed size -> fixed, reproducible summation
 // tree, independent of how the scan kernel was segmented).

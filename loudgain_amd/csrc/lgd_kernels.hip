@@ -146,10 +146,6 @@ struct ScanCfg {
   static constexpr int NV = (16 * C + HALO / 4 + 1 + 63) / 64;
   // frames per streamed step: the largest divisor of C not above 8
   static constexpr int U = lgd_unroll(C);
-  // every lane's chunk is cut into two sub-chunks [0, H1) and [H1, C) that run as
-  // two independent, interleaved recurrences (ILP 2 per wave; H2 <= H1)
-  static constexpr int H1 = lgd_h1(C);
-  static constexpr int H2 = C - H1;
 };
 
 // (launch bounds: G waves per workgroup, >= 2 waves per SIMD wanted -> <= 256 VGPRs;
@@ -346,129 +342,61 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     cfilt_ptr Fk = F0;
     asm volatile("" : "+s"(Fk));
     if (dbg & 2) continue;
-    // start states of the two sub-chunks, as (q1, q2) and (p1, p2)
-    double qs[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, ps[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    // The fixed-channel variants run ONE stream per lane (H2 = 0: the two-stream loops below
-    // fold away).  Two interleaved half-chunks were worth 8 % while both waves of a SIMD
-    // competed at equal priority; with the phase priorities (LGD_PRIO_*) the other wave
-    // hides the dependency latency and the split only costs its combine steps (measured:
-    // one stream -2 % at 48 kHz, -5 % at 44.1 kHz, -10 % at 22.05 kHz).  The
-    // run-time-channel kernel keeps two streams.
-    constexpr int H1 = (G != 0) ? C : K::H1, H2 = C - H1;
+    // start state of this lane's chunk, as (q1, q2) and (p1, p2)
+    double qs[2] = {0.0, 0.0}, ps[2] = {0.0, 0.0};
+    // (One recurrence per lane.  Two interleaved half-chunks per lane were worth 8 % while
+    // both waves of a SIMD competed at equal priority; with the phase priorities (LGD_PRIO_*)
+    // the other wave hides the dependency latency and the split only cost its combine
+    // steps: one stream measured -2 % at 48 kHz, -5 % at 44.1 kHz, -10 % at 22.05 kHz.)
     if (filt) {
-      // ---- A: zero-state runs of q' = x/ra, p' = q'/pa over both sub-chunks (4 FMAs
-      // per sample and stream, the two streams interleaved).  (1 - z^-1)^2 commutes
-      // with both filters, so second differences of the last four q', p' give the
-      // zero-state (q, p) at a sub-chunk's end; q', p' stay <= ~C^2 |x| here, so
-      // the differencing costs ~1e-13 |x| at most. ---------------------------------
-      double z[4], z1[4];
+      // ---- A: zero-state run of q' = x/ra, p' = q'/pa over the chunk (4 FMAs per
+      // sample).  (1 - z^-1)^2 commutes with both filters, so second differences of the
+      // last four q', p' give the zero-state (q, p) at the chunk's end; q', p' stay
+      // <= ~C^2 |x| here, so the differencing costs ~1e-13 |x| at most. -------------
+      double z[4];
       {
-        double qv[2][4], pv[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) qv[h][r] = pv[h][r] = 0.0;
+        double qv[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0};
         // LDS reads run one step ahead of the arithmetic (software pipeline)
-        float xa[2][U];
+        float xa[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          xa[0][u] = LGD_X(u);
-          xa[1][u] = LGD_X(H1 + u);
-        }
-        // drain here, so that inside the loops the only LDS reads in flight are the
+        for (int u = 0; u < U; ++u) xa[u] = LGD_X(u);
+        // drain here, so that inside the loop the only LDS reads in flight are the
         // NEXT step's (hipcc otherwise merges the pre-loop state into the loop and
         // waits for the reads it has just issued)
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-#define LGD_A_STEP(h_, u_)                                                              \
-        do {                                                                            \
-          double t_ = fma(-ra2, qv[h_][1], (double)xa[h_][u_]);                         \
-          const double q0_ = fma(-ra1, qv[h_][0], t_);                                  \
-          t_ = fma(-pa2, pv[h_][1], q0_);                                               \
-          const double p0_ = fma(-pa1, pv[h_][0], t_);                                  \
-          qv[h_][3] = qv[h_][2]; qv[h_][2] = qv[h_][1]; qv[h_][1] = qv[h_][0]; qv[h_][0] = q0_; \
-          pv[h_][3] = pv[h_][2]; pv[h_][2] = pv[h_][1]; pv[h_][1] = pv[h_][0]; pv[h_][0] = p0_; \
-        } while (0)
-        // both streams at once, statement by statement: neighbouring instructions are
-        // independent, so a wave issues back to back instead of waiting ~2 issue slots
-        // for each link of one stream's dependency chain
-#define LGD_A_STEP2(u_)                                                                 \
-        do {                                                                            \
-          double ta_ = fma(-ra2, qv[0][1], (double)xa[0][u_]);                          \
-          double tb_ = fma(-ra2, qv[1][1], (double)xa[1][u_]);                          \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-          const double qa_ = fma(-ra1, qv[0][0], ta_);                                  \
-          const double qb_ = fma(-ra1, qv[1][0], tb_);                                  \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-          ta_ = fma(-pa2, pv[0][1], qa_);                                               \
-          tb_ = fma(-pa2, pv[1][1], qb_);                                               \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-          const double pa_ = fma(-pa1, pv[0][0], ta_);                                  \
-          const double pb_ = fma(-pa1, pv[1][0], tb_);                                  \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-          qv[0][3] = qv[0][2]; qv[0][2] = qv[0][1]; qv[0][1] = qv[0][0]; qv[0][0] = qa_; \
-          qv[1][3] = qv[1][2]; qv[1][2] = qv[1][1]; qv[1][1] = qv[1][0]; qv[1][0] = qb_; \
-          pv[0][3] = pv[0][2]; pv[0][2] = pv[0][1]; pv[0][1] = pv[0][0]; pv[0][0] = pa_; \
-          pv[1][3] = pv[1][2]; pv[1][2] = pv[1][1]; pv[1][1] = pv[1][0]; pv[1][0] = pb_; \
-        } while (0)
-        const int a_end2 = (dbg & 4) ? 0 : H2, a_end1 = (dbg & 4) ? 0 : H1;
-#pragma unroll 2
-        for (int j0 = 0; j0 < a_end2; j0 += U) {  // both streams (x2: the register copies of the read pipeline fold away)
-          float xn[2][U];
+        const int a_end = (dbg & 4) ? 0 : C;
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            xn[0][u] = LGD_X(j0 + U + u);  // (j0 + U < H1 always here, or H1 == H2 and unused)
-            xn[1][u] = LGD_X(H1 + j0 + U + u);
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) LGD_A_STEP2(u);
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            xa[0][u] = xn[0][u];
-            xa[1][u] = xn[1][u];
-          }
-        }
-#pragma unroll (H2 == 0 ? C / U : 1)
-        for (int j0 = a_end2; j0 < a_end1; j0 += U) {  // the longer first sub-chunk alone
+        for (int j0 = 0; j0 < a_end; j0 += U) {
           float xn[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
+          for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);  // (one step past the chunk at the end: slack)
 #pragma unroll
-          for (int u = 0; u < U; ++u) LGD_A_STEP(0, u);
+          for (int u = 0; u < U; ++u) {
+            double t = fma(-ra2, qv[1], (double)xa[u]);
+            const double q0 = fma(-ra1, qv[0], t);
+            t = fma(-pa2, pv[1], q0);
+            const double p0 = fma(-pa1, pv[0], t);
+            qv[3] = qv[2]; qv[2] = qv[1]; qv[1] = qv[0]; qv[0] = q0;
+            pv[3] = pv[2]; pv[2] = pv[1]; pv[1] = pv[0]; pv[0] = p0;
+          }
 #pragma unroll
-          for (int u = 0; u < U; ++u) xa[0][u] = xn[u];
+          for (int u = 0; u < U; ++u) xa[u] = xn[u];
         }
-#undef LGD_A_STEP
-#undef LGD_A_STEP2
-        // zero-state end states in the scan basis; the runs assumed a zero input
-        // history: the true x[-1], x[-2] in front of a sub-chunk change its w[0] by
+        // zero-state end state in the scan basis; the run assumed a zero input
+        // history: the true x[-1], x[-2] in front of the chunk change its w[0] by
         // -2x[-1] + x[-2] and its w[1] by x[-1] (g = their effect on the end state)
-        double zz[2][4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const double q1 = (qv[h][0] - 2.0 * qv[h][1]) + qv[h][2];
-          const double q2 = (qv[h][1] - 2.0 * qv[h][2]) + qv[h][3];
-          const double p1 = (pv[h][0] - 2.0 * pv[h][1]) + pv[h][2];
-          const double p2 = (pv[h][1] - 2.0 * pv[h][2]) + pv[h][3];
-          const double xm1 = (double)(h ? LGD_X(H1 - 1) : LGD_X(-1));
-          const double xm2 = (double)(h ? LGD_X(H1 - 2) : LGD_X(-2));
-          const double dw0 = fma(-2.0, xm1, xm2), dw1 = xm1;
-          const auto *g0 = h ? Fk->gH2[0] : Fk->gH1[0];
-          const auto *g1 = h ? Fk->gH2[1] : Fk->gH1[1];
-          zz[h][0] = fma(g1[0], dw1, fma(g0[0], dw0, q1));
-          zz[h][1] = fma(g1[1], dw1, fma(g0[1], dw0, alpha * fma(-beta, q2, q1)));
-          zz[h][2] = fma(g1[2], dw1, fma(g0[2], dw0, gamma_ * p1));
-          zz[h][3] = fma(g1[3], dw1, fma(g0[3], dw0, gamma_ * p2));
-        }
-        // whole chunk: z = M^H2 z1 + z2 (block lower triangular transition)
-        {
-          const auto *P = Fk->MH2;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) z1[r] = zz[0][r];
-          z[0] = fma(P[1], z1[1], fma(P[0], z1[0], zz[1][0]));
-          z[1] = fma(P[5], z1[1], fma(P[4], z1[0], zz[1][1]));
-          z[2] = fma(P[11], z1[3], fma(P[10], z1[2], fma(P[9], z1[1], fma(P[8], z1[0], zz[1][2]))));
-          z[3] = fma(P[15], z1[3], fma(P[14], z1[2], fma(P[13], z1[1], fma(P[12], z1[0], zz[1][3]))));
-        }
+        const double q1 = (qv[0] - 2.0 * qv[1]) + qv[2];
+        const double q2 = (qv[1] - 2.0 * qv[2]) + qv[3];
+        const double p1 = (pv[0] - 2.0 * pv[1]) + pv[2];
+        const double p2 = (pv[1] - 2.0 * pv[2]) + pv[3];
+        const double xm1 = (double)LGD_X(-1), xm2 = (double)LGD_X(-2);
+        const double dw0 = fma(-2.0, xm1, xm2), dw1 = xm1;
+        const auto *g0 = Fk->gC[0];
+        const auto *g1 = Fk->gC[1];
+        z[0] = fma(g1[0], dw1, fma(g0[0], dw0, q1));
+        z[1] = fma(g1[1], dw1, fma(g0[1], dw0, alpha * fma(-beta, q2, q1)));
+        z[2] = fma(g1[2], dw1, fma(g0[2], dw0, gamma_ * p1));
+        z[3] = fma(g1[3], dw1, fma(g0[3], dw0, gamma_ * p2));
       }
 
       // (latency-bound section: issue priority over the SIMD's other wave, which is most
@@ -521,28 +449,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         }
       }
       // z is now the exact state at the END of each lane's chunk; the state at
-      // its START is the previous lane's (lane 0: the carry); the second sub-chunk
-      // starts from M^H1 (start) + z1.  Back to (q, p).
-      double sv[2][4];
+      // its START is the previous lane's (lane 0: the carry).  Back to (q, p).
+      double sv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sv[0][r] = lgd_wave_shr1(z[r], cin[r]);
+        sv[r] = lgd_wave_shr1(z[r], cin[r]);
         cin[r] = __shfl(z[r], LGD_WAVE - 1, LGD_WAVE);
       }
-      {
-        const auto *P = Fk->MH1;
-        sv[1][0] = fma(P[1], sv[0][1], fma(P[0], sv[0][0], z1[0]));
-        sv[1][1] = fma(P[5], sv[0][1], fma(P[4], sv[0][0], z1[1]));
-        sv[1][2] = fma(P[11], sv[0][3], fma(P[10], sv[0][2], fma(P[9], sv[0][1], fma(P[8], sv[0][0], z1[2]))));
-        sv[1][3] = fma(P[15], sv[0][3], fma(P[14], sv[0][2], fma(P[13], sv[0][1], fma(P[12], sv[0][0], z1[3]))));
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        qs[h][0] = sv[h][0];
-        qs[h][1] = fma(-inv_alpha, sv[h][1], sv[h][0]) * inv_beta;
-        ps[h][0] = sv[h][2] * dcg;
-        ps[h][1] = sv[h][3] * dcg;
-      }
+      qs[0] = sv[0];
+      qs[1] = fma(-inv_alpha, sv[1], sv[0]) * inv_beta;
+      ps[0] = sv[2] * dcg;
+      ps[1] = sv[3] * dcg;
       __builtin_amdgcn_s_setprio(LGD_PRIO_C);
     }
 
@@ -642,146 +559,60 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       }                                                                                 \
     } while (0)
     if (filt) {
-      // two interleaved streams: sub-chunk h covers chunk frames [h * H1, ...)
-      double xh[2][2], eh[2] = {0.0, 0.0}, en[2] = {0.0, 0.0};
-      xh[0][0] = (double)LGD_X(-1); xh[0][1] = (double)LGD_X(-2);
-      xh[1][0] = (double)LGD_X(H1 - 1); xh[1][1] = (double)LGD_X(H1 - 2);
-      float w[2][U + HX];  // per stream: frames j0-HX .. j0+U-1 of its sub-chunk
+      double xh[2], eh = 0.0, en = 0.0;
+      xh[0] = (double)LGD_X(-1); xh[1] = (double)LGD_X(-2);
+      float w[U + HX];  // frames j0-HX .. j0+U-1 of the chunk
       // without the interpolator the next U frames are fetched a step ahead of
       // the arithmetic; with it the window is re-read per step (shifting an
       // 11..23-frame window through registers costs more than the LDS reads)
       constexpr bool PIPE = (TP == 0);
       if constexpr (PIPE) {
 #pragma unroll
-        for (int i = 0; i < U + HX; ++i) {
-          w[0][i] = LGD_X(i - HX);
-          w[1][i] = LGD_X(H1 + i - HX);
-        }
+        for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(i - HX);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see phase A
       }
-#define LGD_C_STEP(h_, u_, jc_)                                                         \
-      do {                                                                              \
-        const double x_ = (double)w[h_][HX + (u_)];                                     \
-        double t_ = fma(-2.0, xh[h_][0], x_) + xh[h_][1]; /* w[n], exact */             \
-        xh[h_][1] = xh[h_][0];                                                          \
-        xh[h_][0] = x_;                                                                 \
-        t_ = fma(-ra2, qs[h_][1], t_);                                                  \
-        const double q0_ = fma(-ra1, qs[h_][0], t_);                                    \
-        t_ = fma(-pa2, ps[h_][1], q0_);                                                 \
-        const double p0_ = fma(-pa1, ps[h_][0], t_);                                    \
-        /* y / pb0 = p0 + (pb1/pb0) p1 + (pb2/pb0) p2; pb0^2 is applied per sub-block */ \
-        const double y_ = fma(c2, ps[h_][1], fma(c1, ps[h_][0], p0_));                  \
-        if constexpr (G == 0) {                                                         \
-          const double y2_ = y_ * y_;                                                   \
-          const bool lo_ = (jc_) < bnd;                                                 \
-          eh[h_] += lo_ ? y2_ : 0.0;                                                    \
-          en[h_] += lo_ ? 0.0 : y2_;                                                    \
-        } else {                                                                        \
-          eh[h_] = fma(y_, y_, eh[h_]);                                                 \
-        }                                                                               \
-        qs[h_][1] = qs[h_][0]; qs[h_][0] = q0_;                                         \
-        ps[h_][1] = ps[h_][0]; ps[h_][0] = p0_;                                         \
-      } while (0)
-      // both streams, statement by statement (see LGD_A_STEP2)
-#define LGD_C_STEP2(u_, ja_, jb_)                                                       \
-      do {                                                                              \
-        const double xa_ = (double)w[0][HX + (u_)];                                     \
-        const double xb_ = (double)w[1][HX + (u_)];                                     \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        double ta_ = fma(-2.0, xh[0][0], xa_);                                          \
-        double tb_ = fma(-2.0, xh[1][0], xb_);                                          \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        ta_ += xh[0][1];                                                                \
-        tb_ += xh[1][1];                                                                \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        xh[0][1] = xh[0][0]; xh[0][0] = xa_;                                            \
-        xh[1][1] = xh[1][0]; xh[1][0] = xb_;                                            \
-        ta_ = fma(-ra2, qs[0][1], ta_);                                                 \
-        tb_ = fma(-ra2, qs[1][1], tb_);                                                 \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        const double qa_ = fma(-ra1, qs[0][0], ta_);                                    \
-        const double qb_ = fma(-ra1, qs[1][0], tb_);                                    \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        ta_ = fma(-pa2, ps[0][1], qa_);                                                 \
-        tb_ = fma(-pa2, ps[1][1], qb_);                                                 \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        const double pa_ = fma(-pa1, ps[0][0], ta_);                                    \
-        const double pb_ = fma(-pa1, ps[1][0], tb_);                                    \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        double ya_ = fma(c1, ps[0][0], pa_);                                            \
-        double yb_ = fma(c1, ps[1][0], pb_);                                            \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        ya_ = fma(c2, ps[0][1], ya_);                                                   \
-        yb_ = fma(c2, ps[1][1], yb_);                                                   \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        if constexpr (G == 0) {                                                         \
-          const double y2a_ = ya_ * ya_, y2b_ = yb_ * yb_;                              \
-          const bool loa_ = (ja_) < bnd, lob_ = (jb_) < bnd;                            \
-          eh[0] += loa_ ? y2a_ : 0.0;                                                   \
-          eh[1] += lob_ ? y2b_ : 0.0;                                                   \
-          en[0] += loa_ ? 0.0 : y2a_;                                                   \
-          en[1] += lob_ ? 0.0 : y2b_;                                                   \
-        } else {                                                                        \
-          eh[0] = fma(ya_, ya_, eh[0]);                                                 \
-          eh[1] = fma(yb_, yb_, eh[1]);                                                 \
-          __builtin_amdgcn_sched_barrier(0);                                            \
-        }                                                                               \
-        qs[0][1] = qs[0][0]; qs[0][0] = qa_;                                            \
-        qs[1][1] = qs[1][0]; qs[1][0] = qb_;                                            \
-        ps[0][1] = ps[0][0]; ps[0][0] = pa_;                                            \
-        ps[1][1] = ps[1][0]; ps[1][0] = pb_;                                            \
-      } while (0)
-      const int c_end2 = (dbg & 16) ? 0 : H2, c_end1 = (dbg & 16) ? 0 : H1;
-#pragma unroll 2
-      for (int j0 = 0; j0 < c_end2; j0 += U) {  // both streams
-        float xn[2][U];
-        if constexpr (PIPE) {
+      const int c_end = (dbg & 16) ? 0 : C;
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            xn[0][u] = LGD_X(j0 + U + u);
-            xn[1][u] = LGD_X(H1 + j0 + U + u);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < U + HX; ++i) {
-            w[0][i] = LGD_X(j0 + i - HX);
-            w[1][i] = LGD_X(H1 + j0 + i - HX);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) LGD_C_STEP2(u, j0 + u, H1 + j0 + u);
-        LGD_PEAKS_BLOCK(w[0], j0);
-        LGD_PEAKS_BLOCK(w[1], H1 + j0);
-        if constexpr (PIPE) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            w[0][HX + u] = xn[0][u];
-            w[1][HX + u] = xn[1][u];
-          }
-        }
-      }
-#pragma unroll (H2 == 0 ? C / U : 1)
-      for (int j0 = c_end2; j0 < c_end1; j0 += U) {  // the longer first sub-chunk alone
+      for (int j0 = 0; j0 < c_end; j0 += U) {
         float xn[U];
         if constexpr (PIPE) {
 #pragma unroll
           for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
         } else {
 #pragma unroll
-          for (int i = 0; i < U + HX; ++i) w[0][i] = LGD_X(j0 + i - HX);
+          for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) LGD_C_STEP(0, u, j0 + u);
-        LGD_PEAKS_BLOCK(w[0], j0);
+        for (int u = 0; u < U; ++u) {
+          const double x = (double)w[HX + u];
+          double t = fma(-2.0, xh[0], x) + xh[1];  // w[n], exact
+          xh[1] = xh[0];
+          xh[0] = x;
+          t = fma(-ra2, qs[1], t);
+          const double q0 = fma(-ra1, qs[0], t);
+          t = fma(-pa2, ps[1], q0);
+          const double p0 = fma(-pa1, ps[0], t);
+          // y / pb0 = p0 + (pb1/pb0) p1 + (pb2/pb0) p2; pb0^2 is applied per sub-block
+          const double y = fma(c2, ps[1], fma(c1, ps[0], p0));
+          if constexpr (G == 0) {
+            const double y2 = y * y;
+            const bool lo = (j0 + u) < bnd;
+            eh += lo ? y2 : 0.0;
+            en += lo ? 0.0 : y2;
+          } else {
+            eh = fma(y, y, eh);
+          }
+          qs[1] = qs[0]; qs[0] = q0;
+          ps[1] = ps[0]; ps[0] = p0;
+        }
+        LGD_PEAKS_BLOCK(w, j0);
         if constexpr (PIPE) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) w[0][HX + u] = xn[u];
+          for (int u = 0; u < U; ++u) w[HX + u] = xn[u];
         }
       }
-#undef LGD_C_STEP
-#undef LGD_C_STEP2
-      e = eh[0] + eh[1];
-      e_next = en[0] + en[1];
+      e = eh;
+      e_next = en;
     } else {
       // channel mapped EBUR128_UNUSED (e.g. LFE): no loudness, peaks only
 #pragma unroll 1
