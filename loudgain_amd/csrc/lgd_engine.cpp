@@ -351,8 +351,8 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   const size_t lds_cap = 160 * 1024;  // per CU == per workgroup limit on gfx950
   if (forced) {
     for (const int *p = lgd_chunk_table; *p; ++p)
-      if (*p == forced && s100 % *p == 0 && (nch <= 2 || *p == 25 || *p == 35) &&
-          lgd_scan_lds_bytes(*p, (int)nch, tp, nch > 2 && !(nch == 3 || nch == 4 || nch == 6 || nch == 8)) <= lds_cap)
+      if (*p == forced && s100 % *p == 0 && (nch <= 2 || *p == 25 || (*p == 35 && nch != 5)) &&
+          lgd_scan_lds_bytes(*p, (int)nch, tp, nch > 2 && !((nch >= 3 && nch <= 6) || nch == 8)) <= lds_cap)
         return *p;
     return 0;
   }
@@ -364,8 +364,9 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   static const int pref_many[] = {25, 35, 45, 49, 50, 63, 75, 0};
   // 3, 4, 6 (5.1), 8 (7.1) planes per workgroup: the two short chunks compiled for them
   static const int pref_51[] = {35, 25, 0};
-  const bool multi = nch == 3 || nch == 4 || nch == 6 || nch == 8;  // planar specialisations exist
-  const int *pref = nch <= 2 ? pref_fast : (multi ? pref_51 : pref_many);
+  static const int pref_5[] = {25, 0};  // 5 planes: C = 35 spills and loses to the run-time-channel kernel
+  const bool multi = (nch >= 3 && nch <= 6) || nch == 8;  // planar specialisations exist
+  const int *pref = nch <= 2 ? pref_fast : (nch == 5 ? pref_5 : (multi ? pref_51 : pref_many));
   const bool generic = nch > 2 && !multi;
   for (int pass = 0; pass < 2; ++pass)
     for (const int *p = pref; *p; ++p)
@@ -466,16 +467,28 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   const uint64_t min_seg = (uint64_t)std::max<long>(4, 3 * c->p_warm_sb);
   if (!c->p_seg_sb && seg_sb < min_seg) seg_sb = min_seg;  // keep the warm-up overhead bounded
   if (seg_sb < 1) seg_sb = 1;
-  // workgroups of many waves (3+ channels) fill a CU in coarser steps: give their tracks
-  // 1.5x the segments (measured on 5.1: 334 -> 500 workgroups, -30 % kernel time)
-  uint64_t seg_sb_multi = c->p_seg_sb ? seg_sb : std::max<uint64_t>(min_seg, (seg_sb * 2 + 2) / 3);
+  // Workgroups of many waves (3+ channels) fill a CU in coarse steps: at 3 waves per SIMD a
+  // CU holds floor(12 / channels) of them (16 waves per CU for the 9..16-channel kernel),
+  // and a launch with a few more workgroups than slots runs two rounds.  Tracks of each
+  // such layout together get one workgroup per slot (measured on 5 channels: 600 -> 512
+  // workgroups, 1.31 -> see DESIGN 6.0).
+  uint64_t multi_sb[LGD_GROUP_CH + 1] = {0};
+  for (uint32_t t = 0; t < n; ++t)
+    if (tracks[t].channels > 2)
+      multi_sb[std::min<unsigned>(tracks[t].channels, LGD_GROUP_CH)] += (uint64_t)c->meta[t].n_sb;
+  uint64_t seg_sb_multi[LGD_GROUP_CH + 1];
+  for (unsigned k = 0; k <= LGD_GROUP_CH; ++k) {
+    const unsigned per_cu = k == 0 ? 1 : (k > 8 ? std::max(1u, 16u / k) : std::max(1u, 12u / k));
+    const uint64_t slots = (uint64_t)c->n_cu * per_cu;
+    seg_sb_multi[k] = c->p_seg_sb ? seg_sb : std::max<uint64_t>(min_seg, (multi_sb[k] + slots - 1) / slots);
+  }
 
   for (uint32_t t = 0; t < n; ++t) {
     const lgd_track &tr = tracks[t];
     LgdTrackMeta &m = c->meta[t];
     const int s100 = m.s100;
     const uint64_t nsb = (uint64_t)m.n_sb;
-    const uint64_t seg_t = tr.channels > 2 ? seg_sb_multi : seg_sb;
+    const uint64_t seg_t = tr.channels > 2 ? seg_sb_multi[std::min<unsigned>(tr.channels, LGD_GROUP_CH)] : seg_sb;
     const uint64_t nseg = nsb ? (nsb + seg_t - 1) / seg_t : 1;
     m.n_seg = (int)nseg;
     m.peak_off = (long long)c->total_peak_floats;
@@ -490,7 +503,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         g.nch = g_nch;
         g.nch_total = tr.channels;
         g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
-        g.chunk = ((g_nch <= 4 || g_nch == 6 || g_nch == 8) && g_nch == tr.channels)
+        g.chunk = ((g_nch <= 6 || g_nch == 8) && g_nch == tr.channels)
                       ? pick_chunk(c->p_chunk, s100, g_nch, g.tp) : 0;
         // fast kernels: mono / stereo with a chunk that divides the sub-block; anything else
         // (more channels, channel groups, rates such as 11 025 Hz) goes to the generic kernel,

@@ -118,7 +118,7 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // TP  0 = no interpolator (>= 192 kHz or disabled), 4 = 4x, 2 = 2x
 // LDS layout of a staged tile.
 //  G == 0 (run-time channel count): interleaved as in memory, frame stride nch.
-//  G >= 1 (compiled for 1, 2, 3, 4, 6 = 5.1 and 8 = 7.1): PLANAR, one plane per channel, and every lane's C-frame chunk is
+//  G >= 1 (compiled for 1 .. 6 and 8): PLANAR, one plane per channel, and every lane's C-frame chunk is
 //  followed by PAD unused floats so that the lane stride C + PAD is odd: 64 lanes
 //  reading the same chunk position then hit 32 different banks (an even stride,
 //  e.g. interleaved stereo, costs 2..32-way ds_read conflicts).
@@ -723,8 +723,7 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
     if (tp == 2) return launch_scan_t<C, 1, 2>(segs, n_seg, F, nch, s);
     return launch_scan_t<C, 1, 0>(segs, n_seg, F, nch, s);
   }
-  if (nch > 2) {  // 3, 4, 6 or 8 planes per workgroup (2.1, quad, 5.1, 7.1): the short chunks only
-                  // (5 planes measured slower than the run-time-channel kernel: not compiled)
+  if (nch > 2) {  // 3 .. 6 or 8 planes per workgroup (2.1, quad, 5.0, 5.1, 7.1): the short chunks only
     if constexpr (C == 25 || C == 35) {  // (45 / 50 spill 50+ registers with the interpolator)
 #define LGD_DISPATCH_G(g_)                                                              \
       if (nch == g_) {                                                                  \
@@ -732,7 +731,7 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
         if (tp == 2) return launch_scan_t<C, g_, 2>(segs, n_seg, F, nch, s);            \
         return launch_scan_t<C, g_, 0>(segs, n_seg, F, nch, s);                         \
       }
-      LGD_DISPATCH_G(3) LGD_DISPATCH_G(4) LGD_DISPATCH_G(6) LGD_DISPATCH_G(8)
+      LGD_DISPATCH_G(3) LGD_DISPATCH_G(4) LGD_DISPATCH_G(5) LGD_DISPATCH_G(6) LGD_DISPATCH_G(8)
 #undef LGD_DISPATCH_G
     }
     return hipErrorInvalidValue;
@@ -758,7 +757,7 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, c
     if (tp == 2) return launch_scan_generic<2>(nch, segs, n_seg, F, s);
     return launch_scan_generic<0>(nch, segs, n_seg, F, s);
   }
-  if (nch > 8 || nch == 7 || nch == 5) return hipErrorInvalidValue;
+  if (nch > 8 || nch == 7) return hipErrorInvalidValue;
   switch (chunk) {
     case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, F, s);
     case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, F, s);

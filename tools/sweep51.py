@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import torch
 from loudgain_amd import synth
 from loudgain_amd.device import DeviceScanner
-for rate, ch, tp, wpc in [(48000, 6, True, 8), (44100, 6, True, 8), (48000, 3, True, 8), (48000, 8, True, 8), (48000, 5, True, 8), (48000, 12, True, 8), (44100, 2, True, 8), (96000, 2, True, 8), (44100, 1, True, 8)]:
+for rate, ch, tp, wpc in [(48000, 3, True, 8), (48000, 4, True, 8), (48000, 5, True, 8), (44100, 5, True, 8), (48000, 6, True, 8), (44100, 6, True, 8), (48000, 7, True, 8), (48000, 8, True, 8), (48000, 12, True, 8), (48000, 24, True, 8)]:
     frames = int(172800000 * 2 / ch)
     pcm = synth.track_torch(frames, ch, rate, seed=1, device="cuda")
     sc = DeviceScanner(0); sc.set_param("overlap", 0); sc.set_param("waves_per_cu", wpc); sc.plan([pcm], rate, true_peak=tp)
