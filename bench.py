@@ -52,6 +52,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
     ap.add_argument("--minutes", type=float, default=60.0)
+    ap.add_argument("--material", default="steps", choices=["steps", "adversarial", "silence", "noise"],
+                    help="steps: SURVEY 8d programme material; adversarial: constant-amplitude fs/4 sine "
+                         "sampled on its peaks (no true-peak window can be pruned)")
+    ap.add_argument("--no-tp-prune", action="store_true")
+    ap.add_argument("--debug-counters", action="store_true",
+                    help="measurement build only (LOUDSCAN_LIB=.../libloudscan_hip_dbg.so): true-peak pruning statistics of one scan")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--seg-subblocks", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=0)
@@ -89,7 +95,14 @@ def main():
     rate, ch = 48000, 2
     frames = int(round(args.minutes * 60 * rate))
     true_peak = args.workload == "c3"
-    pcm = synth.track_torch(frames, ch, rate, seed=rank, device=dev)
+    if args.material == "adversarial":
+        pcm = synth.adversarial_torch(frames, ch, device=dev)
+    elif args.material == "silence":
+        pcm = torch.zeros((frames, ch), dtype=torch.float32, device=dev)
+    elif args.material == "noise":   # stationary noise, no level steps, no sine
+        pcm = synth.track_torch(frames, ch, rate, seed=rank, step_s=1e9, device=dev, sine=False)
+    else:
+        pcm = synth.track_torch(frames, ch, rate, seed=rank, device=dev)
     torch.cuda.synchronize()
 
     sc = DeviceScanner(local_rank)
@@ -105,6 +118,8 @@ def main():
         sc.set_param("debug", args.debug)
     if args.serial:
         sc.set_param("overlap", 0)
+    if args.no_tp_prune:
+        sc.set_param("tp_prune", 0)
     stream = torch.cuda.Stream(device=dev)
 
     # Kernel timing for the roofline.  In the timed region below consecutive scans
@@ -167,6 +182,17 @@ def main():
         except Exception:
             traffic = None
 
+    if args.debug_counters and rank == 0:
+        import ctypes as C
+        buf = (C.c_ulonglong * 8)()
+        sc.L.lgd_debug_counters(buf, 1)
+        sc.plan([pcm], rate, true_peak=true_peak, album=False)
+        sc.execute(stream)
+        sc.fetch()
+        sc.L.lgd_debug_counters(buf, 1)
+        names = ["windows", "candidates", "queue_passes", "own_bit_iters", "queue_overflow_tiles",
+                 "tiles_with_candidates", "tiles", "publishes"]
+        print(json.dumps({"tp_debug_counters_one_scan": dict(zip(names, list(buf)[:8]))}), file=sys.stderr, flush=True)
     if rank == 0:
         tr = results[0][0]
         line = {

@@ -62,7 +62,8 @@ typedef struct {
   double lra;            /* LU; 0.0 when no short-term block is listed */
   double peak;           /* max over channels of max(true peak, sample peak) */
   double sample_peak;    /* max over channels */
-  double true_peak;      /* max over channels of the interpolated peak (0 if off) */
+  double true_peak;      /* max over channels of ebur128_true_peak = max(interpolated, sample);
+                            0 when the plan had no LGD_FLAG_TRUE_PEAK */
   double rel_threshold;  /* relative gate, energy units */
   double sum_abs;        /* sum of block energies >= absolute gate */
   double sum_rel;        /* sum of block energies >= relative gate */
@@ -102,10 +103,14 @@ const char *lgd_last_error(void);
  * sub-blocks per wave segment, 0 = auto), "warm_subblocks" (K-filter warm-up
  * before a segment, default 2 = 200 ms: measured 2e-16 relative to any longer warm-up), "waves_per_cu" (auto segmentation target), "timing" (1 = bracket the scan kernel
  * with hipEvents for lgd_kernel_ms_stats, default; 0 = no event packets), "overlap"
- * (1 = consecutive lgd_execute calls alternate between the caller's stream and an
- * internal one so that independent scans pipeline, default; 0 = strictly serial on
- * the caller's stream, which is what kernel timings should be taken in), "album_slots"
- * (short-term slots in album record 1, see the multi-GPU album below; 0 = this plan's own). */
+ * (0 = every scan runs on the caller's stream, in stream order like any kernel, default;
+ * 1 = consecutive lgd_execute calls alternate between the caller's stream and an internal
+ * one so that independent scans pipeline -- then a scan may still be READING its PCM after
+ * the caller's stream has drained: do not overwrite or free a track buffer before
+ * lgd_fetch, or order the writer behind the scans with lgd_join), "album_slots"
+ * (short-term slots in album record 1, see the multi-GPU album below; 0 = this plan's own),
+ * "tp_prune" (1 = the true-peak interpolator is evaluated only where it can exceed the peak
+ * already found -- exact, default; 0 = everywhere: the reference mode of the pruning tests). */
 int lgd_set_param(lgd_ctx *ctx, const char *name, long value);
 
 /* Build the segment table + workspace for a batch of tracks (host work and
@@ -121,10 +126,13 @@ int lgd_plan_albums(lgd_ctx *ctx, const lgd_track *tracks, uint32_t n_tracks,
 /* Enqueue the whole scan (hipStream_t as void*; NULL = default stream): K-weight +
  * block-energy + peak kernel(s), gating / LRA epilogue and, with LGD_FLAG_ALBUM, the
  * album stages.  Asynchronous, no allocation.  Work enqueued on `hip_stream` before
- * the call is ordered before the scan; the scan itself may run on an internal stream
- * (see "overlap"), so its results are defined after lgd_fetch, not after a
- * synchronisation of `hip_stream` alone. */
+ * the call is ordered before the scan; with "overlap" 1 the scan itself may run on an
+ * internal stream, so its results are defined (and its PCM may be reused) after lgd_fetch
+ * or behind lgd_join, not after a synchronisation of `hip_stream` alone. */
 int lgd_execute(lgd_ctx *ctx, void *hip_stream);
+/* "overlap" 1 only: make `hip_stream` wait for every scan enqueued so far (they may run on
+ * an internal stream), e.g. before the stream re-uploads PCM into a buffer being scanned. */
+int lgd_join(lgd_ctx *ctx, void *hip_stream);
 /* Synchronise the streams used by the last lgd_execute calls and copy results out.
  * `album` may be NULL; otherwise it has room for one record per album of the plan. */
 int lgd_fetch(lgd_ctx *ctx, lgd_track_result *tracks_out, lgd_album_result *album);
@@ -163,8 +171,8 @@ int lgd_convert_s16(const short *dev_in, float *dev_out, uint64_t n_samples, voi
  * (sum_c w_c sum y^2, not yet divided by the block length) */
 int lgd_copy_subblock_energies(lgd_ctx *ctx, uint32_t track, double *host_out, uint64_t cap,
                                uint64_t *n_out);
-/* per-channel peaks of one track (ebur128_sample_peak / the interpolated peak of
- * ebur128_true_peak, scan.c:303,371 take them channel by channel); true_peak is 0
+/* per-channel peaks of one track: ebur128_sample_peak and ebur128_true_peak =
+ * max(interpolated, sample) (scan.c:303,371 take them channel by channel); true_peak is 0
  * when the plan had no LGD_FLAG_TRUE_PEAK; either output may be NULL */
 int lgd_copy_channel_peaks(lgd_ctx *ctx, uint32_t track, double *sample_peak, double *true_peak,
                            uint32_t cap_channels);
@@ -175,6 +183,9 @@ int lgd_last_kernel_ms(lgd_ctx *ctx, float *scan_ms, float *total_ms);
  * kernel, mean of the whole enqueue; synchronises on their events */
 int lgd_kernel_ms_stats(lgd_ctx *ctx, uint32_t last_n, float *scan_mean, float *scan_min,
                         float *total_mean, uint32_t *n_used);
+/* lgd_kernel_ms_stats' scan figure covers every kernel that reads PCM: the scan kernels and
+ * the true-peak kernel behind them; this is the scan kernels alone */
+int lgd_scan_only_ms_stats(lgd_ctx *ctx, uint32_t last_n, float *mean, float *min_ms);
 /* plan geometry (for DESIGN/bench reporting) */
 int lgd_plan_info(lgd_ctx *ctx, uint64_t *n_segments, uint64_t *n_subblocks, uint32_t *chunk,
                   uint64_t *pcm_bytes, uint64_t *warm_bytes);

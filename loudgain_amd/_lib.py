@@ -46,6 +46,7 @@ DEVICE_SYMBOLS = [
     "lgd_fetch", "lgd_album_record1", "lgd_album_record2", "lgd_album_stage2",
     "lgd_album_stage3", "lgd_copy_subblock_energies", "lgd_last_kernel_ms",
     "lgd_kernel_ms_stats", "lgd_plan_info", "lgd_album_join", "lgd_copy_channel_peaks", "lgd_plan_albums", "lgd_convert_s16",
+    "lgd_join", "lgd_scan_only_ms_stats",
 ]
 
 
@@ -84,6 +85,7 @@ def load():
     L.lgd_album_record2.argtypes = [vp, C.POINTER(vp)]
     L.lgd_album_stage2.argtypes = [vp, vp, C.c_uint32, vp]
     L.lgd_album_join.argtypes = [vp, vp]
+    L.lgd_join.argtypes = [vp, vp]
     L.lgd_copy_channel_peaks.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32]
     L.lgd_album_stage3.argtypes = [vp, vp, C.c_uint32, vp]
     L.lgd_copy_subblock_energies.argtypes = [vp, C.c_uint32, vp, C.c_uint64,
@@ -91,6 +93,7 @@ def load():
     L.lgd_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.lgd_kernel_ms_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.lgd_scan_only_ms_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.lgd_plan_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_uint64)]

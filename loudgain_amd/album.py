@@ -172,6 +172,9 @@ class DistributedAlbumScanner:
         import torch
         self.group = group
         self.always_exchange = always_exchange
+        # back-to-back album scans pipeline on the engine's two streams (the track buffers
+        # stay untouched until fetch(): the contract of "overlap" 1)
+        scanner.set_param("overlap", 1)
         self.shard = DeviceShard(scanner, tracks, rates, true_peak, group=group)
         self.shard.reduce_stream = torch.cuda.Stream(device=self.shard.device)
         self.buffers = {}

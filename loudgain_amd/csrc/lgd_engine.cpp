@@ -24,12 +24,15 @@ extern "C" const int lgd_chunk_table[];
 extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic);
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, const LgdSeg *segs,
                                       int n_seg, const LgdFilt *F, hipStream_t s);
+extern "C" hipError_t lgd_launch_tp(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
+                                    int rows_max, const LgdFilt *F, hipStream_t s);
 extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_slices,
                                                 const LgdTrackMeta *meta, int n_tracks,
                                                 const double *E, double *Z, double *st,
                                                 const float *peaks, double *p1, double *p2,
-                                                double *pmax_s, double *res, double abs_gate,
-                                                double rel_factor, int do_tp, hipStream_t s);
+                                                double *pmax_s, double *res, unsigned *hint,
+                                                double abs_gate, double rel_factor, int do_tp,
+                                                hipStream_t s);
 extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
                                      double minus20, hipStream_t s);
 extern "C" hipError_t lgd_launch_album_part1(const double *res, const LgdAlbumMeta *albums,
@@ -186,6 +189,30 @@ static void design_interp(int factor, float tp[36]) {
   }
 }
 
+// Pruning bound of the interpolator (lgd_scan_kernel, pk_lb): every output of a window is at
+// most L1 * max|x| of it, L1 = the largest sum of |taps| of a non-trivial phase (4x: 1.8642
+// for phase 2, 1.6312 for phases 1 / 3; 2x: 2.3068).  The kernel evaluates the taps in fp32
+// through sums and differences of mirrored samples: ~14 roundings of 2^-24 each on
+// quantities bounded by the same L1 * max|x| (and 2.34 * max|x| for the (sum, difference) form of
+// phases 1 / 3), i.e. < 4e-6 relative.  The factor below leaves 10x that margin, so a window with
+// max|x| <= tp_thr * P can never produce a computed output above P.
+static float interp_prune_factor(int factor) {
+  if (!factor) return 0.f;
+  const double pi = 3.14159265358979323846264338327950288;
+  double l1[4] = {0, 0, 0, 0};
+  for (int j = 0; j < 49; ++j) {
+    const double m = (double)j - 24.0;
+    double c = 1.0;
+    if (std::fabs(m) > 0.000001) c = std::sin(m * pi / factor) / (m * pi / factor);
+    c *= 0.5 * (1.0 - std::cos(2.0 * pi * j / 48.0));
+    if (std::fabs(c) > 0.000001) l1[j % factor] += std::fabs((double)(float)c) + 1e-9;
+  }
+  double worst = 0.0;
+  for (int f = 1; f < factor; ++f) worst = std::max(worst, l1[f]);
+  float r = (float)(1.0 / (worst * (1.0 + 4e-5)));
+  return std::nextafterf(r, 0.f);
+}
+
 // ------------------------------------------------------------------ context --
 struct Group {  // tracks sharing (rate, channels) -> one scan launch
   unsigned rate, nch, nch_total;  // nch: channels (waves) per workgroup
@@ -193,14 +220,15 @@ struct Group {  // tracks sharing (rate, channels) -> one scan launch
   bool generic;
   LgdFilt F;
   size_t seg_begin, seg_count;
+  int rows_max;  // most true-peak candidate rows (tiles x channels) of any of its segments
 };
 static const size_t MAX_GROUPS = 64;  // distinct (rate, channels) pairs per plan
 static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at most
 
 struct lgd_ctx {
   int device = 0;
-  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 1,
-       p_album_slots = 0;
+  long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 0,
+       p_album_slots = 0, p_tp_prune = 1;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -213,7 +241,7 @@ struct lgd_ctx {
   std::vector<LgdAlbumMeta> albums;
   std::vector<Group> groups;
   uint64_t total_sb = 0, total_e = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0,
-           warm_bytes = 0, rec1_len = 4;
+           warm_bytes = 0, rec1_len = 4, total_tp_rows = 0;
   // device workspace.  Everything a scan writes exists twice (WorkSet): scans
   // alternate between the two sets and between two streams (see lgd_execute).
   struct WorkSet {
@@ -227,12 +255,14 @@ struct lgd_ctx {
     const double *lra_base = nullptr;  // short-term list of the album (set by stage 2)
     uint64_t lra_n = 0;
     float *d_peaks = nullptr;
+    unsigned *d_hint = nullptr;     // per track and channel: peak found so far (LgdSeg::hint), 0 between scans
+    unsigned long long *d_tp_rows = nullptr;  // true-peak candidate rows, one per (tile, channel) (LgdSeg::tp_rows)
     LgdSeg *d_segs = nullptr;       // descriptors carry pointers into this set's E / peaks
     LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
     LgdRange *h_album_range = nullptr;  // pinned
     size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_segs = 0,
            cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0, cap_rec1 = 0, cap_album = 0,
-           cap_part1 = 0, cap_rec2 = 0, cap_heads = 0, cap_album_ranges = 0, cap_pmax = 0;
+           cap_part1 = 0, cap_rec2 = 0, cap_heads = 0, cap_album_ranges = 0, cap_pmax = 0, cap_hint = 0, cap_tp_rows = 0;
     hipEvent_t ev_scan = nullptr;   // caller-stream marker the internal stream waits for
     hipEvent_t ev_done = nullptr;   // end of this set's scan + epilogue (lgd_album_join)
     hipEvent_t ev_album = nullptr;  // end of a caller-driven album stage 3 on this set
@@ -241,6 +271,7 @@ struct lgd_ctx {
   int n_sets = 1;     // 2 pipelined; 4 when the caller drives the album stages (their exchange lags the scans)
   int cur_set = 0;    // set of the last lgd_execute
   hipStream_t side = nullptr;
+  hipEvent_t ev_join = nullptr;  // lgd_join: end of the internal stream's work so far
   LgdSlice *d_slices = nullptr;
   LgdFilt *d_filt = nullptr;  // [MAX_GROUPS] per-group kernel constants
   LgdTrackMeta *d_meta = nullptr;
@@ -249,7 +280,7 @@ struct lgd_ctx {
   hipStream_t last_stream = nullptr;
   // ring of (start, scan kernel done, all done) event triples, one per execute
   static const int EV_RING = 64;
-  hipEvent_t ev[EV_RING][3];
+  hipEvent_t ev[EV_RING][4];  // start, scan + true-peak kernels done, all done, scan kernels done
   uint64_t n_exec = 0;
   double abs_gate, rel_factor, minus20;
 };
@@ -288,7 +319,7 @@ extern "C" lgd_ctx *lgd_create(int device) {
   bool ok = true;
   memset(c->ev, 0, sizeof(c->ev));
   for (int i = 0; i < lgd_ctx::EV_RING; ++i)
-    for (int j = 0; j < 3; ++j) ok = ok && hipEventCreate(&c->ev[i][j]) == hipSuccess;
+    for (int j = 0; j < 4; ++j) ok = ok && hipEventCreate(&c->ev[i][j]) == hipSuccess;
   for (auto &w : c->ws) {
     ok = ok && hipMalloc((void **)&w.d_album_range, sizeof(LgdRange)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&w.h_album_range, sizeof(LgdRange)) == hipSuccess;
@@ -297,6 +328,7 @@ extern "C" lgd_ctx *lgd_create(int device) {
     ok = ok && hipEventCreateWithFlags(&w.ev_album, hipEventDisableTiming) == hipSuccess;
   }
   ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->d_filt, MAX_GROUPS * sizeof(LgdFilt)) == hipSuccess;
   if (!ok) {
     fail(LGD_ENOMEM, "lgd_create: allocation failed");
@@ -313,7 +345,7 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
   for (auto &w : c->ws) {
     void *ptrs[] = {w.d_E, w.d_Z, w.d_rec1, w.d_res, w.d_album, w.d_part1, w.d_rec2, w.d_peaks,
                     w.d_segs, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a, w.d_heads,
-                    w.d_album_ranges, w.d_pmax};
+                    w.d_album_ranges, w.d_pmax, w.d_hint, w.d_tp_rows};
     for (void *p : ptrs)
       if (p) (void)hipFree(p);
     if (w.h_album_range) (void)hipHostFree(w.h_album_range);
@@ -325,8 +357,9 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
   for (void *p : ptrs2)
     if (p) (void)hipFree(p);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < lgd_ctx::EV_RING; ++i)
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 4; ++j)
       if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
   delete c;
 }
@@ -342,6 +375,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "timing")) { c->p_timing = value; return LGD_OK; }  // hipEvent brackets on/off
   else if (!strcmp(name, "overlap")) c->p_overlap = value;  // 0: every scan on the caller's stream
   else if (!strcmp(name, "album_slots")) c->p_album_slots = value;  // short-term slots of album record 1
+  else if (!strcmp(name, "tp_prune")) c->p_tp_prune = value;  // 0: evaluate every interpolator window
   else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
   c->planned = false;
   return LGD_OK;
@@ -405,7 +439,10 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   c->slices.clear();
   c->groups.clear();
   c->total_sb = c->total_e = c->total_st = c->total_peak_floats = c->pcm_bytes = c->warm_bytes = 0;
+  c->total_tp_rows = 0;
 
+  uint64_t total_ch = 0;
+  if ((uint64_t)n * LGD_MAX_CHANNELS > 0x7fffffffull) return fail(LGD_EUNSUP, "too many tracks in one plan");
   for (uint32_t t = 0; t < n; ++t) {
     const lgd_track &tr = tracks[t];
     // ebur128_init's own argument checks
@@ -420,6 +457,9 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     m.s100 = (int)((tr.rate + 5) / 10);
     m.nch = (int)tr.channels;
     m.album = album_of_track ? (int)album_of_track[t] : 0;
+    m.hint_off = (int)total_ch;
+    m.pad = 0;
+    total_ch += tr.channels;
     const uint64_t nsb = tr.frames / (uint64_t)m.s100;
     if (nsb > 0x7fffffffull) return fail(LGD_EUNSUP, "track %u too long", t);
     m.n_sb = (int)nsb;
@@ -518,6 +558,8 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         design_kfilter((double)g.rate, g.F.pb, g.F.pa, g.F.ra);
         design_scan_basis(g.F, g.chunk);
         design_interp(g.tp, g.F.tp);
+        g.F.tp_thr = interp_prune_factor(g.tp);
+        g.F.tp_prune = c->p_tp_prune ? 1 : 0;
         g.F.pbn[0] = g.F.pb[1] / g.F.pb[0];
         g.F.pbn[1] = g.F.pb[2] / g.F.pb[0];
         g.F.pb0sq = g.F.pb[0] * g.F.pb[0];
@@ -525,11 +567,12 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         g.F.s100 = s100;
         g.F.pad = (int)c->p_debug;
         g.seg_begin = g.seg_count = 0;
+        g.rows_max = 0;
         it = group_of.emplace(key, c->groups.size()).first;
         c->groups.push_back(g);
         group_segs.emplace_back();
       }
-      const Group &g = c->groups[it->second];
+      Group &g = c->groups[it->second];
       const long long tile_f = 64LL * g.chunk;
       const int warm_tiles =
           c->p_warm_sb ? (int)(((long long)c->p_warm_sb * s100 + tile_f - 1) / tile_f) : 0;
@@ -549,6 +592,16 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         sg.ch0 = (int)ch0;
         sg.nch_total = (int)tr.channels;
         sg.pad = 0;
+        sg.hint = (unsigned *)(uintptr_t)m.hint_off;
+        sg.tp_rows = nullptr;
+        if (g.tp) {  // one row of candidate bits per tile and channel of this workgroup
+          const long long n_tiles = (sg.f_peak_end - sg.f0 + tile_f - 1) / tile_f;
+          const long long rows = n_tiles * (long long)g_nch;
+          if (rows > 0x7fffffffLL) return fail(LGD_EUNSUP, "track %u: segment too long", t);
+          sg.tp_rows = (unsigned long long *)(uintptr_t)c->total_tp_rows;
+          c->total_tp_rows += (uint64_t)rows;
+          g.rows_max = std::max(g.rows_max, (int)rows);
+        }
         sg.peak_out = (float *)(uintptr_t)(m.peak_off + (long long)(sgi * 2ull * tr.channels));
         group_segs[it->second].push_back(sg);
         if (sb0) c->warm_bytes += (uint64_t)warm_tiles * tile_f * g_nch * 4ull;
@@ -607,12 +660,18 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if ((rc = ensure(&w.d_res, &w.cap_res, (size_t)n * LGR_STRIDE))) return rc;
     if ((rc = ensure(&w.d_peaks, &w.cap_peaks, c->total_peak_floats))) return rc;
     if ((rc = ensure(&w.d_segs, &w.cap_segs, c->segs.size()))) return rc;
+    if ((rc = ensure(&w.d_tp_rows, &w.cap_tp_rows, (size_t)c->total_tp_rows))) return rc;
+    if ((rc = ensure(&w.d_hint, &w.cap_hint, (size_t)total_ch * LGD_HINT_STRIDE))) return rc;
+    HIPCHK(hipMemset(w.d_hint, 0, std::max<size_t>(1, (size_t)total_ch * LGD_HINT_STRIDE) * sizeof(unsigned)));
     if ((rc = ensure(&w.d_ranges, &w.cap_ranges, n))) return rc;
     // the host descriptors hold offsets; each set gets its own pointers
     std::vector<LgdSeg> segs(c->segs);
     for (LgdSeg &sg : segs) {
       sg.e_out = w.d_E + (uintptr_t)sg.e_out;
       sg.peak_out = w.d_peaks + (uintptr_t)sg.peak_out;
+      sg.hint = w.d_hint + (uintptr_t)sg.hint * LGD_HINT_STRIDE;
+      // (sg.tp_rows holds an element offset; only interpolating groups use it)
+      sg.tp_rows = w.d_tp_rows + (uintptr_t)sg.tp_rows;
     }
     for (uint32_t t = 0; t < n; ++t) {
       c->ranges[t].off = c->meta[t].st_off;
@@ -704,6 +763,17 @@ extern "C" int lgd_album_join(lgd_ctx *c, void *hip_stream) {
   return LGD_OK;
 }
 
+// Order `hip_stream` behind every scan enqueued so far (with "overlap" 1 a scan may still be
+// reading its PCM on the internal stream after the caller's stream has drained).
+extern "C" int lgd_join(lgd_ctx *c, void *hip_stream) {
+  if (!c) return fail(LGD_EINVAL, "lgd_join: null context");
+  if (!c->executed || c->n_sets < 2) return LGD_OK;  // everything ran on the caller's stream
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventRecord(c->ev_join, c->side));
+  HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, c->ev_join, 0));
+  return LGD_OK;
+}
+
 extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   if (!c || !c->planned) return fail(LGD_ESTATE, "lgd_execute before lgd_plan");
   HIPCHK(hipSetDevice(c->device));
@@ -736,10 +806,18 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
     HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, g.generic ? 1 : 0, w.d_segs + g.seg_begin,
                            (int)g.seg_count, c->d_filt + gi, s));
   }
+  if (c->p_timing) HIPCHK(hipEventRecord(ev[3], s));
+  // the interpolator over the windows the scan kernels flagged (every channel's peak hints are
+  // final once all scan kernels of the plan are done: a track's channels share one launch)
+  for (size_t gi = 0; gi < c->groups.size(); ++gi) {
+    const Group &g = c->groups[gi];
+    HIPCHK(lgd_launch_tp(g.chunk, (int)g.nch, g.tp, w.d_segs + g.seg_begin, (int)g.seg_count, g.rows_max,
+                         c->d_filt + gi, s));
+  }
   if (c->p_timing) HIPCHK(hipEventRecord(ev[1], s));
   HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, w.d_E, w.d_Z,
-                                   w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_pmax, w.d_res, c->abs_gate,
-                                   c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
+                                   w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_pmax, w.d_res, w.d_hint,
+                                   c->abs_gate, c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
   HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, s));
   c->executed = true;
   if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))
@@ -888,7 +966,9 @@ extern "C" int lgd_copy_channel_peaks(lgd_ctx *c, uint32_t track, double *sample
       t = std::max(t, (double)pp[m.nch + ch]);
     }
     if (sample_peak) sample_peak[ch] = sp;
-    if (true_peak) true_peak[ch] = tp ? t : 0.0;
+    // ebur128_true_peak's value, max(interpolated, sample): the kernel skips interpolator
+    // windows that cannot exceed the peak already found, so only this maximum is defined
+    if (true_peak) true_peak[ch] = tp ? std::max(t, sp) : 0.0;
   }
   return LGD_OK;
 }
@@ -922,6 +1002,26 @@ extern "C" int lgd_kernel_ms_stats(lgd_ctx *c, uint32_t last_n, float *scan_mean
   if (scan_min) *scan_min = smin;
   if (total_mean) *total_mean = (float)(ta / (double)n);
   if (n_used) *n_used = (uint32_t)n;
+  return LGD_OK;
+}
+
+// the scan kernels alone (without the true-peak kernel that lgd_kernel_ms_stats' figure includes)
+extern "C" int lgd_scan_only_ms_stats(lgd_ctx *c, uint32_t last_n, float *mean, float *min_ms) {
+  if (!c || !c->n_exec) return fail(LGD_ESTATE, "no executed plan");
+  uint64_t n = std::min<uint64_t>(std::min<uint64_t>(last_n ? last_n : lgd_ctx::EV_RING,
+                                                     lgd_ctx::EV_RING), c->n_exec);
+  double sa = 0;
+  float smin = 1e30f;
+  for (uint64_t i = 0; i < n; ++i) {
+    hipEvent_t *ev = c->ev[(c->n_exec - 1 - i) % lgd_ctx::EV_RING];
+    float a = 0;
+    HIPCHK(hipEventSynchronize(ev[2]));
+    HIPCHK(hipEventElapsedTime(&a, ev[0], ev[3]));
+    sa += a;
+    smin = std::min(smin, a);
+  }
+  if (mean) *mean = (float)(sa / (double)n);
+  if (min_ms) *min_ms = smin;
   return LGD_OK;
 }
 

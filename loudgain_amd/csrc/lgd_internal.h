@@ -20,6 +20,13 @@ struct LgdSeg {
   int ch0;               // first channel this workgroup handles (channel groups of
   int nch_total;         // streams with > 16 channels; otherwise 0 and the channel count)
   int pad;
+  unsigned long long *tp_rows;  // true-peak candidates of this segment: one 64-bit row per (tile k,
+                         // channel ch of this workgroup) at tp_rows[k * nch + ch], bit l = lane l's
+                         // chunk of the tile is flagged; null without interpolator
+  unsigned *hint;        // [nch_total][LGD_HINT_STRIDE] (LGD_HINT_SLOTS used) per-channel peak found so far anywhere in the
+                         // track (float bits, only ever a lower bound of the final peak; 16-B
+                         // aligned): what the true-peak pruning of other segments may rely on;
+                         // zeroed between scans
 };
 
 // Per-(rate, chunk) constants, passed by value as a kernel argument.
@@ -37,6 +44,9 @@ struct LgdFilt {
   double P[6][16];   // transition over C * 2^j frames, j = 0..5 (scan basis, row-major;
                      // block lower triangular: P[.][2], [3], [6], [7] are zero)
   float tp[36];      // 4x: phases 1..3 x 12 taps; 2x: phase 1 x 24 taps (A.5)
+  float tp_thr;      // true-peak pruning: a window whose largest |x| is <= tp_thr * (peak found so
+                     // far) cannot raise the peak (tp_thr < 1 / max_phase sum |c|, rounding included)
+  int tp_prune;      // 0: every window is evaluated (reference mode of the pruning tests)
   int lps;           // lanes (C-frame chunks) per 100 ms sub-block = s100 / C
   int pad;           // debug builds: floor-measurement mode bits
   int pskip;         // bit j: P[j]'s shelf block (entries 10,11,14,15) is < 1e-19 -> skipped
@@ -52,6 +62,10 @@ constexpr int lgd_unroll(int C) {
 // blocks, one workgroup per slice (fixed size -> fixed, reproducible summation
 // tree, independent of how the scan kernel was segmented).
 #define LGD_SLICE 1024
+// words per channel of the peak-hint array (one per XCD: blockIdx mod 8)
+#define LGD_HINT_SLOTS 8
+// words from one channel's slots to the next channel's: a 64-B line per channel
+#define LGD_HINT_STRIDE 16
 
 struct LgdSlice {
   int track;
@@ -72,6 +86,9 @@ struct LgdTrackMeta {
   int slice_off;      // first epilogue slice of this track
   int n_slices;       // ceil((n_sb - 3) / LGD_SLICE), 0 if n_sb < 4
   int album;          // album of this track (albums are runs of consecutive tracks)
+  int hint_off;       // first of this track's nch channels in the peak-hint array (LgdSeg::hint;
+                      // LGD_HINT_STRIDE words per channel)
+  int pad;
 };
 
 // one album of a plan: tracks [t0, t1), their epilogue slices [slice0, slice1)

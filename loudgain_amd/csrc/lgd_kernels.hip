@@ -40,6 +40,8 @@
 #include "lgd_internal.h"
 
 #define LGD_WAVE 64
+// entries (u16) of a wave's true-peak candidate queue in LDS, behind the staged tile
+#define LGD_TPQ_CAP 512
 
 // Wave priorities per section of a tile (measured, tools/prio_sweep.sh): the latency-bound
 // sections (staging, wave scan) first, and phase C above phase A -- the wave closer to
@@ -106,6 +108,47 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, LGD_WAVE));
   return v;
 }
+// the same through the DPP paths, result wave-uniform (an SGPR); v_max_f32 drops NaNs
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max_f32_uniform(float v) {
+  v = fmaxf(v, dpp_f32<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_f32<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_f32<0x141, 0xF>(v));  // row_half_mirror
+  v = fmaxf(v, dpp_f32<0x140, 0xF>(v));  // row_mirror: every lane holds its row's maximum
+  v = fmaxf(v, dpp_f32<0x142, 0xA>(v));  // row_bcast:15 into rows 1 and 3
+  v = fmaxf(v, dpp_f32<0x143, 0xC>(v));  // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), LGD_WAVE - 1));
+}
+// inclusive prefix sum over the wave (Kogge-Stone inside the rows of 16, row totals by row_bcast)
+__device__ __forceinline__ int wave_incl_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+#ifdef LGD_DEBUG_MODES
+// measurement builds: [0] interpolator windows seen, [1] candidates, [2] queue passes,
+// [3] own-bits iterations, [4] tiles that overflowed the queue, [5] tiles with candidates, [6] tiles
+__device__ unsigned long long lgd_dbg_counters[8];
+extern "C" hipError_t lgd_debug_counters(unsigned long long *out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(lgd_dbg_counters), 8 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(lgd_dbg_counters), z, sizeof(z));
+  }
+  return e;
+}
+#define LGD_DBG_COUNT(i_, v_) do { if (lane == 0) atomicAdd(&lgd_dbg_counters[i_], (unsigned long long)(v_)); } while (0)
+#else
+#define LGD_DBG_COUNT(i_, v_) do { } while (0)
+#endif
 
 // ------------------------------------------------------------ scan kernel ---
 // One workgroup per segment, one WAVEFRONT PER CHANNEL: the nch waves of a
@@ -210,23 +253,44 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 #else
   constexpr int dbg = 0;
 #endif
-  // interpolator coefficients, unique values only (the 49-tap prototype is
-  // symmetric: 4x phase 3 mirrors phase 1, phase 2 and the 2x phase mirror
-  // themselves) -> 18 / 12 SGPRs instead of 36 / 24
-  float tpa[12 + 1], tpb[6 + 1];
-  f32x2 tpsd[6 + 1];  // 4x: halved (sum, difference) coefficients of the mirrored phase pair
-#pragma unroll
-  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpsd[i] = (f32x2){F.tp[18 + 2 * i], F.tp[19 + 2 * i]};
-#pragma unroll
-  for (int i = 0; i < (TP ? 12 : 0); ++i) tpa[i] = F.tp[i];
-#pragma unroll
-  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpb[i] = F.tp[12 + i];
-
   double cin[4] = {0.0, 0.0, 0.0, 0.0};  // wave-uniform filter state entering the tile
   double acc = 0.0;       // this lane's share of sub-block `cur`
   int cur = 0;            // sub-block (relative to the segment) being summed
   int cur_q = 0;          // chunk index (relative to f0) where `cur` starts
-  float pk_s = 0.f, pk_t = 0.f;
+  float pk_s = 0.f;
+  // True-peak pruning (exact).  An interpolated output is sum_k c_k x[n-k], so it cannot exceed
+  // L1 * (largest |x| it reads), L1 = largest sum |c_k| of a phase.  pk_lb is a peak this
+  // channel of this track is already known to reach (own samples so far and what other
+  // segments published in sg.hint): outputs with L1 * max|x| <= pk_lb cannot raise
+  // max(true peak, sample peak) -- the value ebur128_true_peak reports (E9) -- and are
+  // not evaluated.  The result is bit-identical to evaluating everything.
+  float pk_lb = 0.f, pk_pub = 0.f;  // pk_pub: the largest peak this wave has published or seen published
+  // mc of lane 63 of the previous tile; +inf in front of the first tile (its frames were not looked at)
+  float mc_carry = __builtin_inff();
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 hint_nx[2] = {(u32x4)(0u), (u32x4)(0u)};  // slot loads in flight (taken one tile later)
+  const float tp_thr = F.tp_thr;
+  const int tp_prune = F.tp_prune;
+  // Publishing: an atomic max on this workgroup's slot when the wave knows a peak 1 dB above
+  // everything it has published or seen.  All slots of a channel share one 64-B line, i.e.
+  // one memory-side atomic unit (~26 ns per atomic, measured: 2000 waves publishing their
+  // first tile at once stalled every one of them ~50 us at its next vmcnt wait).  So in its
+  // first two tiles only every 16th workgroup publishes; the others have polled those
+  // values by their third tile and publish only what exceeds them.
+  const int k_first = -sg.n_warm_tiles;
+  const bool early_pub = (blockIdx.x & 15) == 0;
+#define LGD_PUBLISH(k_)                                                                         \
+  do {                                                                                          \
+    if (pk_lb > pk_pub * 1.122f && (early_pub || (k_) >= k_first + 2)) { /* wave-uniform */     \
+      if (lane == 0)                                                                            \
+        (void)__hip_atomic_fetch_max(hint_base + (blockIdx.x & (LGD_HINT_SLOTS - 1)),           \
+                                     (unsigned)__float_as_int(pk_lb), __ATOMIC_RELAXED,         \
+                                     __HIP_MEMORY_SCOPE_AGENT);                                 \
+      pk_pub = pk_lb;                                                                           \
+    }                                                                                           \
+  } while (0)
+  unsigned LGD_GLOBAL *const hint_base =
+      (unsigned LGD_GLOBAL *)sg.hint + (size_t)((G ? 0 : sg.ch0) + ch) * LGD_HINT_STRIDE;
 
   const int n_main = (int)((sg.f_peak_end - sg.f0 + K::TILE_F - 1) / K::TILE_F);
 
@@ -324,13 +388,44 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     }
 #undef LGD_STORE_VEC
     __syncthreads();
+    // What the other segments of this channel have found so far.  The value asked for during
+    // the PREVIOUS tile is taken here, where no load is outstanding (the staging above has
+    // consumed them all), and the next one is requested before the next tile's loads: no
+    // wait on it can ever wait for those.
+    if constexpr (TP != 0) {
+      // (One polled word per channel does not work: an agent-scope atomic load of a word that
+      // every wave of the track polls is served by one memory channel at ~13 ns apiece --
+      // 76 000 of them per C3 launch took longer than the scan itself -- and atomics on it
+      // serialise the same way, each wave then waiting for its own at the next staging.  Hence:
+      // LGD_HINT_SLOTS words per channel, a wave publishes to the slot of its workgroup
+      // (blockIdx mod 8: workgroups that share an XCD share a slot), only when it knows a peak
+      // 1 dB above everything it has seen, and polls with PLAIN cached loads.  Cached copies go
+      // stale, but the tile streams evict them within a tile or two (L1 32 KB per CU, L2 4 MB
+      // per XCD) and any older value is still a valid lower bound.  Inline asm, or the optimiser
+      // would hoist a plain load out of the tile loop; the hand-placed wait is needed because
+      // the compiler does not count asm loads (its own counted waits stay correct: these loads
+      // are older than every load they wait for).)
+      // ("+v": the uses below must not be scheduled above this wait.  After a tile that ran
+      // phase C the youngest outstanding operation is that tile's row store -- issued last on
+      // purpose -- and need not be waited for: vmcnt(1).)
+      if (k > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(hint_nx[0]), "+v"(hint_nx[1]) : : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hint_nx[0]), "+v"(hint_nx[1]) : : "memory");
+      {
+        const unsigned a_ = max(max(hint_nx[0].x, hint_nx[0].y), max(hint_nx[0].z, hint_nx[0].w));
+        const unsigned b_ = max(max(hint_nx[1].x, hint_nx[1].y), max(hint_nx[1].z, hint_nx[1].w));
+        const float seen = __int_as_float(__builtin_amdgcn_readfirstlane((int)max(a_, b_)));
+        pk_lb = fmaxf(pk_lb, seen);
+        pk_pub = fmaxf(pk_pub, seen);
+      }
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                   : "=&v"(hint_nx[0]), "=&v"(hint_nx[1]) : "v"(hint_base) : "memory");
+    }
     if (k + 1 < n_main) LGD_PREFETCH(k + 1); else pf_valid = false;
     __builtin_amdgcn_s_setprio(LGD_PRIO_A);
 
     // this lane's chunk of this wave's channel: frames [tb + lane*C, +C), frame
     // stride nch floats, streamed from LDS U frames at a time
     constexpr int U = K::U;
-    constexpr int HX = K::HX;
     // this lane's chunk; LGD_X(j) = frame j of it (j < 0: history in the previous chunk)
     const float *chunk = LL::PLANAR
         ? lds + ch * PLANE + (K::HALO + slot_shift) + lane * LL::STRIDE  // + PAD folded below
@@ -356,6 +451,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       double z[4];
       {
         double qv[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0};
+        float ma = 0.f;  // warm-up tiles only: largest |x| (the first peak estimate to publish)
         // LDS reads run one step ahead of the arithmetic (software pipeline)
         float xa[U];
 #pragma unroll
@@ -397,6 +493,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         z[1] = fma(g1[1], dw1, fma(g0[1], dw0, alpha * fma(-beta, q2, q1)));
         z[2] = fma(g1[2], dw1, fma(g0[2], dw0, gamma_ * p1));
         z[3] = fma(g1[3], dw1, fma(g0[3], dw0, gamma_ * p2));
+        if constexpr (TP != 0) {
+          if (k < 0) {  // (a second pass over the chunk: two tiles per segment only)
+#pragma unroll
+            for (int j = 0; j < C; ++j) ma = fmaxf(ma, fabsf(LGD_X(j)));
+            pk_lb = fmaxf(pk_lb, wave_max_f32_uniform(ma));
+            LGD_PUBLISH(k);
+          }
+        }
       }
 
       // (latency-bound section: issue priority over the SIMD's other wave, which is most
@@ -465,16 +569,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 
     if (k < 0) continue;  // warm-up tile: only the carry matters
 
-    // ---- C: real run: y, energy, peaks ---------------------------------
-    // frames >= n_frames were staged as zeros; their interpolator outputs do
-    // not exist in the reference (it stops at the last input frame)
-    const long long lane_f = tb + (long long)lane * C;
-    const bool tail = (tb + K::TILE_F > n_frames);  // block-uniform
-    int nvalid = C;
-    if (tail) {
-      const long long rem = n_frames - lane_f;
-      nvalid = rem < 0 ? 0 : (rem > C ? C : (int)rem);
-    }
+    // ---- C: real run: y, energy, sample peak, true-peak candidates -------
     double e = 0.0, e_next = 0.0;  // e_next: generic kernel, frames past a sub-block boundary
     // generic (run-time channel count) kernel: the chunk length need not divide the
     // sub-block length; frames j < bnd of this chunk belong to sub-block sb_l, the
@@ -486,105 +581,28 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       const unsigned rem = (unsigned)(sb_l + 1) * (unsigned)s100 - fl;
       bnd = rem < (unsigned)C ? (int)rem : C;
     }
-    // sample peaks and the polyphase interpolator over one window `wv` of U frames
-    // starting at chunk frame jb: U x NPH independent accumulation chains, tap-major,
-    // so that neighbouring instructions never depend on each other and share the
-    // coefficient SGPR
-    // fold U interpolated magnitudes into the running peak; only the tile that holds the
-    // end of the track masks outputs past the last input frame (block-uniform branch, so
-    // the other tiles pay no per-sample compare + select)
-#define LGD_TP_FOLD(m_, jb)                                                             \
+    float mc = 0.f;  // largest |x| of this lane's chunk
+#define LGD_STEP_PEAKS(xs, step_)                                                       \
     do {                                                                                \
-      if (__builtin_expect(tail, 0)) {                                                  \
-        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                                \
-          pk_t = fmaxf(pk_t, ((jb) + u_ < nvalid) ? (m_)[u_] : 0.f);                    \
-        asm volatile("" ::: "memory"); /* keep this a branch, not selects */            \
-      } else {                                                                          \
-        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) pk_t = fmaxf(pk_t, (m_)[u_]);  \
-      }                                                                                 \
-    } while (0)
-#define LGD_PEAKS_BLOCK(wv, jb)                                                         \
-    do {                                                                                \
-      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) pk_s = fmaxf(pk_s, fabsf(wv[HX + u_])); \
-      if constexpr (TP == 4) {                                                          \
-        /* phases 1 and 3 mirror each other, phase 2 is symmetric: per output sample six  */ \
-        /* (sum, difference) pairs of window samples feed one packed FMA for (y1 + y3,    */ \
-        /* y1 - y3) / 2 and one FMA for y2 -- 24 instructions instead of 36 FMAs;         */ \
-        /* max(|y1|, |y3|) = |y1 + y3| / 2 + |y1 - y3| / 2                                  */ \
-        f32x2 sd_[U];                                                                   \
-        float o2_[U];                                                                   \
-        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) { sd_[u_] = (f32x2){0.f, 0.f}; o2_[u_] = 0.f; } \
-        _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) {                              \
-          const f32x2 csd_ = tpsd[k_];                                                  \
-          const float c2_ = tpb[k_];                                                    \
-          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                            \
-            const float xa_ = wv[HX + u_ - k_], xb_ = wv[u_ + k_];                      \
-            const f32x2 ab_ = (f32x2){xa_ + xb_, xa_ - xb_};                            \
-            sd_[u_] = __builtin_elementwise_fma(csd_, ab_, sd_[u_]);                    \
-            o2_[u_] = fmaf(c2_, ab_.x, o2_[u_]);                                        \
-          }                                                                             \
-        }                                                                               \
-        if constexpr (G == 0 || G > 2) { /* register-tight variants: fold as they come */ \
-          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                            \
-            float m_ = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));      \
-            if (tail) m_ = ((jb) + u_ < nvalid) ? m_ : 0.f;                             \
-            pk_t = fmaxf(pk_t, m_);                                                     \
-          }                                                                             \
-        } else {                                                                        \
-          float m_[U];                                                                  \
-          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                              \
-            m_[u_] = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));        \
-          LGD_TP_FOLD(m_, jb);                                                          \
-        }                                                                               \
-      } else if constexpr (TP == 2) {                                                   \
-        /* the one non-trivial 2x phase is symmetric: 12 sums + 12 FMAs per sample */   \
-        float o1_[U];                                                                   \
-        _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) o1_[u_] = 0.f;                 \
-        _Pragma("unroll") for (int k_ = 0; k_ < 12; ++k_) {                             \
-          const float c1_ = tpa[k_];                                                    \
-          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_)                              \
-            o1_[u_] = fmaf(c1_, wv[HX + u_ - k_] + wv[u_ + k_], o1_[u_]);               \
-        }                                                                               \
-        if constexpr (G == 0 || G > 2) {                                                \
-          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                            \
-            float m_ = fabsf(o1_[u_]);                                                  \
-            if (tail) m_ = ((jb) + u_ < nvalid) ? m_ : 0.f;                             \
-            pk_t = fmaxf(pk_t, m_);                                                     \
-          }                                                                             \
-        } else {                                                                        \
-          float m_[U];                                                                  \
-          _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) m_[u_] = fabsf(o1_[u_]);     \
-          LGD_TP_FOLD(m_, jb);                                                          \
-        }                                                                               \
-      }                                                                                 \
+      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) mc = fmaxf(mc, fabsf((xs)[u_])); \
     } while (0)
     if (filt) {
       double xh[2], eh = 0.0, en = 0.0;
       xh[0] = (double)LGD_X(-1); xh[1] = (double)LGD_X(-2);
-      float w[U + HX];  // frames j0-HX .. j0+U-1 of the chunk
-      // without the interpolator the next U frames are fetched a step ahead of
-      // the arithmetic; with it the window is re-read per step (shifting an
-      // 11..23-frame window through registers costs more than the LDS reads)
-      constexpr bool PIPE = (TP == 0);
-      if constexpr (PIPE) {
+      // the next U frames are fetched a step ahead of the arithmetic
+      float w[U];
 #pragma unroll
-        for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(i - HX);
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see phase A
-      }
+      for (int i = 0; i < U; ++i) w[i] = LGD_X(i);
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), see phase A
       const int c_end = (dbg & 16) ? 0 : C;
 #pragma unroll
       for (int j0 = 0; j0 < c_end; j0 += U) {
         float xn[U];
-        if constexpr (PIPE) {
 #pragma unroll
-          for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
-        } else {
-#pragma unroll
-          for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
-        }
+        for (int u = 0; u < U; ++u) xn[u] = LGD_X(j0 + U + u);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const double x = (double)w[HX + u];
+          const double x = (double)w[u];
           double t = fma(-2.0, xh[0], x) + xh[1];  // w[n], exact
           xh[1] = xh[0];
           xh[0] = x;
@@ -605,26 +623,45 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           qs[1] = qs[0]; qs[0] = q0;
           ps[1] = ps[0]; ps[0] = p0;
         }
-        LGD_PEAKS_BLOCK(w, j0);
-        if constexpr (PIPE) {
+        LGD_STEP_PEAKS(w, j0 / U);
 #pragma unroll
-          for (int u = 0; u < U; ++u) w[HX + u] = xn[u];
-        }
+        for (int u = 0; u < U; ++u) w[u] = xn[u];
       }
       e = eh;
       e_next = en;
     } else {
       // channel mapped EBUR128_UNUSED (e.g. LFE): no loudness, peaks only
-#pragma unroll 1
-      for (int j0 = 0; j0 < C; j0 += U) {
-        float w[U + HX];
 #pragma unroll
-        for (int i = 0; i < U + HX; ++i) w[i] = LGD_X(j0 + i - HX);
-        LGD_PEAKS_BLOCK(w, j0);
+      for (int j0 = 0; j0 < C; j0 += U) {
+        float w[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) w[i] = LGD_X(j0 + i);
+        LGD_STEP_PEAKS(w, j0 / U);
       }
     }
-#undef LGD_PEAKS_BLOCK
-#undef LGD_TP_FOLD
+#undef LGD_STEP_PEAKS
+
+    pk_s = fmaxf(pk_s, mc);
+    // ---- true peak: which chunks can matter (exact pruning, see pk_lb).  The interpolator
+    // outputs of a chunk read its own frames and the last HX of the chunk before it, so they
+    // are bounded by L1 * max(mc of this lane, mc of the previous lane); a chunk is flagged
+    // for lgd_tp_kernel when that can exceed the peak found so far.  One 64-bit row per wave
+    // and tile.  (Evaluating the interpolator here, with the tile still in LDS, was measured:
+    // loud passages cluster in time, the workgroup that owns one then runs long after the
+    // other 999 have finished, and the kernel takes as long as that workgroup.  The follow-up
+    // kernel spreads the flagged chunks over the whole GPU.)
+    if constexpr (TP != 0) {
+      pk_lb = fmaxf(pk_lb, wave_max_f32_uniform(mc));
+      LGD_PUBLISH(k);
+      const float thr = tp_prune ? pk_lb * tp_thr : -1.f;
+      const float mprev = __int_as_float(__builtin_amdgcn_update_dpp(
+          __float_as_int(mc_carry), __float_as_int(mc), 0x138, 0xf, 0xf, false));  // wave_shr:1
+      mc_carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mc), LGD_WAVE - 1));
+      const unsigned long long row = __ballot(fmaxf(mc, mprev) > thr);
+      // (the LAST vector-memory operation of the tile: see the vmcnt(1) at the top of the loop)
+      if (lane == 0)
+        ((unsigned long long LGD_GLOBAL *)sg.tp_rows)[(size_t)k * nch + ch] = row;
+    }
 #undef LGD_X
 
     // ---- 100 ms sub-block sums: deterministic per-lane accumulate + wave tree
@@ -667,13 +704,202 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 
   {
     const float s = wave_max_f32(pk_s);
-    const float t = wave_max_f32(pk_t);
     if (lane == 0) {
       ((float LGD_GLOBAL *)sg.peak_out)[ch0 + ch] = s;
-      ((float LGD_GLOBAL *)sg.peak_out)[nch_tot + ch0 + ch] = t;
+      // the interpolated peak of the segment: lgd_tp_kernel raises it (atomic max on the bits)
+      ((float LGD_GLOBAL *)sg.peak_out)[nch_tot + ch0 + ch] = 0.f;
+      if constexpr (TP != 0) {
+        // everything this wave knows, without the 1 dB hysteresis: lgd_tp_kernel prunes with it
+        if (fmaxf(pk_lb, s) > pk_pub)
+          (void)__hip_atomic_fetch_max(hint_base + (blockIdx.x & (LGD_HINT_SLOTS - 1)),
+                                       (unsigned)__float_as_int(fmaxf(pk_lb, s)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 #undef F
+}
+
+// --------------------------------------------------------- true-peak kernel ---
+// E4 (ebur128_check_true_peak / interp_process, reached from scan.c:448) for the chunks that
+// lgd_scan_kernel flagged.  Row r of a segment = (tile k = r / nch, channel r mod nch): a
+// 64-bit mask, bit l = "the C frames [tb + l C, + C) of the tile, tb = f0 + k * 64 C, may
+// hold a new peak".  One wave per row.  The row's flagged chunks are staged LGD_TP_GROUP at a
+// time -- each with the HX frames before it, coalesced loads that mostly hit L2 / Infinity
+// Cache, the scan kernel has just streamed those lines; the next group is in flight while one
+// is evaluated -- and a lane takes one (chunk, step) slot of the group: U output frames from
+// U + HX staged ones, whatever chunk they belong to, so isolated chunks fill passes as well
+// as a loud passage does.  The bound is re-checked against the channel's FINAL peak hint
+// (a pass none of whose lanes can exceed it is skipped) and the non-trivial polyphase
+// branches are evaluated in fp32 (the reference: float data, double
+// accumulate, float result; difference <= 2e-7 against a bar of 1e-4):
+//   4x: phases 1 and 3 mirror each other, phase 2 is symmetric: six (sum, difference) pairs of
+//       window samples feed one packed FMA for (y1 + y3, y1 - y3) / 2 and one FMA for y2 --
+//       24 instructions instead of 36 FMAs; max(|y1|, |y3|) = |y1 + y3| / 2 + |y1 - y3| / 2
+//   2x: the one non-trivial phase is symmetric: 12 sums + 12 FMAs.
+// Frames outside the track read as zero; outputs at or past the track's end do not exist in
+// the reference (it stops at the last input frame) and are masked.  The wave's maximum is
+// folded into the segment's interpolated peak with an atomic max on the float bits
+// (non-negative floats order like their bits).
+#define LGD_TP_WAVES 4
+#define LGD_TP_GROUP 8     // flagged chunks staged together
+#define LGD_TP_CHMAX 100   // frames of one staged chunk at most: C + HX
+#define LGD_TP_NPRE ((LGD_TP_GROUP * LGD_TP_CHMAX + LGD_WAVE - 1) / LGD_WAVE)
+template <int U, int TP>
+__global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
+    const LgdSeg *__restrict__ segs, const LgdFilt *__restrict__ Fg, const int C, const int nch,
+    const unsigned magic_ch, const unsigned magic_ns) {
+  constexpr int HX = (TP == 2) ? 23 : 11;
+  // per wave: the ids of the row's flagged chunks, and the staged frames of one group of them
+  // (chunk c of the group at [c * (C + HX), + C + HX): its HX frames of history, then its own)
+  __shared__ unsigned char chunk_of[LGD_TP_WAVES][LGD_WAVE];
+  __shared__ float stage[LGD_TP_WAVES][LGD_TP_NPRE * LGD_WAVE];  // (whole rounds of 64 lanes are stored)
+  typedef const LgdFilt __attribute__((address_space(4))) *cfilt_ptr;
+  const cfilt_ptr F0 = (cfilt_ptr)Fg;
+  const int lane = threadIdx.x & (LGD_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const LgdSeg sg = segs[blockIdx.x];
+  const long long tile_f = (long long)LGD_WAVE * C;
+  const int n_main = (int)((sg.f_peak_end - sg.f0 + tile_f - 1) / tile_f);
+  const int row = blockIdx.y * LGD_TP_WAVES + wave;
+  if (row >= n_main * nch) return;  // wave-uniform
+  const unsigned long long mask = ((const unsigned long long LGD_GLOBAL *)sg.tp_rows)[row];
+  const int n_chunks = __popcll(mask);
+  if (n_chunks == 0) return;
+  const int k = row / nch, ch = row - k * nch;
+  const int nch_tot = sg.nch_total ? sg.nch_total : nch;
+  const int chan = sg.ch0 + ch;  // channel of the stream (channel groups of wide streams: ch0 > 0)
+  const long long n_frames = sg.n_floats / nch_tot;
+  const long long tb = sg.f0 + (long long)k * tile_f;
+  const gflt_ptr pcm = (gflt_ptr)sg.pcm + chan;
+  const int CH = C + HX, NSTEP = C / U;
+
+  float tpa[12 + 1], tpb[6 + 1];
+  f32x2 tpsd[6 + 1];  // 4x: halved (sum, difference) coefficients of the mirrored phase pair
+#pragma unroll
+  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpsd[i] = (f32x2){F0->tp[18 + 2 * i], F0->tp[19 + 2 * i]};
+#pragma unroll
+  for (int i = 0; i < (TP == 2 ? 12 : 0); ++i) tpa[i] = F0->tp[i];
+#pragma unroll
+  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpb[i] = F0->tp[12 + i];
+  (void)tpa; (void)tpb; (void)tpsd;
+
+  // the channel's peak as the scan kernels left it (LGD_HINT_SLOTS words, all final by now)
+  float thr = -1.f;
+  if (F0->tp_prune) {
+    const unsigned LGD_GLOBAL *h = (const unsigned LGD_GLOBAL *)sg.hint + (size_t)chan * LGD_HINT_STRIDE;
+    unsigned m = 0u;
+#pragma unroll
+    for (int i = 0; i < LGD_HINT_SLOTS; ++i) m = max(m, h[i]);
+    thr = __int_as_float(m) * F0->tp_thr;
+  }
+  // entry o of the table: the o-th set bit of the mask
+  if ((mask >> lane) & 1ull)
+    chunk_of[wave][__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // element e of group g: chunk c = e / CH of the group, frame j = e % CH of its span;
+  // frames outside the track read as zero
+  auto fetch_group = [&](const int g, float (&pre)[LGD_TP_NPRE]) {
+    const int n = min(LGD_TP_GROUP, n_chunks - g * LGD_TP_GROUP);
+    const int E = n * CH;
+#pragma unroll
+    for (int r = 0; r < LGD_TP_NPRE; ++r) {
+      const int e = r * LGD_WAVE + lane;
+      float v = 0.f;
+      if (r * LGD_WAVE < E) {  // (wave-uniform)
+        const int ee = e < E ? e : 0;
+        const int c = (int)(((unsigned)ee * magic_ch) >> 20);
+        const int j = ee - c * CH;
+        const long long f = tb + (long long)chunk_of[wave][g * LGD_TP_GROUP + c] * C - HX + j;
+        const bool in = e < E && f >= 0 && f < n_frames;
+        v = in ? pcm[(in ? f : 0) * nch_tot] : 0.f;
+      }
+      pre[r] = v;
+    }
+  };
+  float pk_t = 0.f;
+  float pre[LGD_TP_NPRE];
+  const int n_groups = (n_chunks + LGD_TP_GROUP - 1) / LGD_TP_GROUP;
+  fetch_group(0, pre);
+  float *const buf = stage[wave];
+  for (int g = 0; g < n_groups; ++g) {
+    const int n = min(LGD_TP_GROUP, n_chunks - g * LGD_TP_GROUP);
+    // (every lane is done reading the previous group: the wave runs in lockstep through the
+    // loop below and the fences order its LDS traffic)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < LGD_TP_NPRE; ++r)
+      if (r * LGD_WAVE < n * CH) buf[r * LGD_WAVE + lane] = pre[r];
+    if (g + 1 < n_groups) fetch_group(g + 1, pre);  // in flight while this group is evaluated
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lane slot v = (chunk c of the group, step st): the U output frames c's frames [st U, + U)
+    const int S = n * NSTEP;
+    for (int v0 = 0; v0 < S; v0 += LGD_WAVE) {
+      const int v = v0 + lane;
+      const bool act = v < S;
+      const int vv = act ? v : 0;
+      const int c = (int)(((unsigned)vv * magic_ns) >> 20);
+      const int st = vv - c * NSTEP;
+      const float *w0 = buf + c * CH + st * U;  // frame (st U - HX) of the chunk
+      float wv[U + HX];
+#pragma unroll
+      for (int i = 0; i < U + HX; ++i) wv[i] = w0[i];
+      float wm = 0.f;
+#pragma unroll
+      for (int i = 0; i < U + HX; ++i) wm = fmaxf(wm, fabsf(wv[i]));
+      const bool need = act && (wm > thr);
+      if (!__any(need)) continue;  // wave-uniform: nothing in this pass can exceed the final peak
+      float m_[U];
+      if constexpr (TP == 4) {
+        f32x2 sd_[U];
+        float o2_[U];
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_) { sd_[u_] = (f32x2){0.f, 0.f}; o2_[u_] = 0.f; }
+#pragma unroll
+        for (int k_ = 0; k_ < 6; ++k_) {
+          const f32x2 csd_ = tpsd[k_];
+          const float c2_ = tpb[k_];
+#pragma unroll
+          for (int u_ = 0; u_ < U; ++u_) {
+            const float xa_ = wv[HX + u_ - k_], xb_ = wv[u_ + k_];
+            const f32x2 ab_ = (f32x2){xa_ + xb_, xa_ - xb_};
+            sd_[u_] = __builtin_elementwise_fma(csd_, ab_, sd_[u_]);
+            o2_[u_] = fmaf(c2_, ab_.x, o2_[u_]);
+          }
+        }
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_) m_[u_] = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));
+      } else {
+        float o1_[U];
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_) o1_[u_] = 0.f;
+#pragma unroll
+        for (int k_ = 0; k_ < 12; ++k_) {
+          const float c1_ = tpa[k_];
+#pragma unroll
+          for (int u_ = 0; u_ < U; ++u_) o1_[u_] = fmaf(c1_, wv[HX + u_ - k_] + wv[u_ + k_], o1_[u_]);
+        }
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_) m_[u_] = fabsf(o1_[u_]);
+      }
+      // output frames f0 + u; those at or past the end of the track do not exist
+      const long long f0 = tb + (long long)chunk_of[wave][g * LGD_TP_GROUP + c] * C + st * U;
+      const long long rem = n_frames - f0;
+      const int nv = !need ? 0 : (rem < 0 ? 0 : (rem > U ? U : (int)rem));
+#pragma unroll
+      for (int u_ = 0; u_ < U; ++u_) pk_t = fmaxf(pk_t, (u_ < nv) ? m_[u_] : 0.f);
+    }
+  }
+  const float t = wave_max_f32_uniform(pk_t);
+  if (t > 0.f && lane == 0)
+    (void)__hip_atomic_fetch_max((unsigned LGD_GLOBAL *)sg.peak_out + nch_tot + chan,
+                                 (unsigned)__float_as_int(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------- launch wrappers ---
@@ -682,13 +908,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
   const int halo = tp == 2 ? 24 : 12;
   const bool planar = !generic;
+  const size_t queue = 0;
   if (planar) {
     const int pad = (chunk % 2 == 0) ? 1 : 0;
     const int plane = (halo + 4 + pad + LGD_WAVE * (chunk + pad) + 4 + 8 + 1) & ~1;
-    return (size_t)nch * plane * sizeof(float);
+    return (size_t)nch * plane * sizeof(float) + queue;
   }
   // (+8 frames: the software-pipelined reads fetch up to one step past the tile)
-  return ((size_t)(LGD_WAVE * chunk + halo + 8) * nch + 4) * sizeof(float);
+  return ((size_t)(LGD_WAVE * chunk + halo + 8) * nch + 4) * sizeof(float) + queue;
 }
 
 template <int C, int G, int TP, bool WIDE = false>
@@ -739,6 +966,29 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
   if (tp == 4) return launch_scan_t<C, 2, 4>(segs, n_seg, F, nch, s);
   if (tp == 2) return launch_scan_t<C, 2, 2>(segs, n_seg, F, nch, s);
   return launch_scan_t<C, 2, 0>(segs, n_seg, F, nch, s);
+}
+
+// rows_max: most rows (tiles x channels) any segment of the launch has
+extern "C" hipError_t lgd_launch_tp(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
+                                    int rows_max, const LgdFilt *F, hipStream_t s) {
+  if (n_seg <= 0 || rows_max <= 0 || !tp) return hipSuccess;
+  const dim3 grid((unsigned)n_seg, (unsigned)((rows_max + LGD_TP_WAVES - 1) / LGD_TP_WAVES));
+  const dim3 block(LGD_WAVE * LGD_TP_WAVES);
+  const int u = lgd_unroll(chunk), hx = tp == 2 ? 23 : 11;
+  const unsigned ch_len = (unsigned)(chunk + hx), nstep = (unsigned)(chunk / u);
+  if (ch_len > LGD_TP_CHMAX) return hipErrorInvalidValue;
+  // x / d == (x * magic) >> 20 over the ranges the kernel divides (checked here, per launch)
+  const unsigned magic_ch = ((1u << 20) + ch_len - 1u) / ch_len, magic_ns = ((1u << 20) + nstep - 1u) / nstep;
+  for (unsigned x = 0; x < LGD_TP_GROUP * ch_len; ++x)
+    if (((x * magic_ch) >> 20) != x / ch_len) return hipErrorInvalidValue;
+  for (unsigned x = 0; x < LGD_TP_GROUP * nstep + LGD_WAVE; ++x)
+    if (((x * magic_ns) >> 20) != x / nstep) return hipErrorInvalidValue;
+  if (u == 5 && tp == 4) hipLaunchKernelGGL((lgd_tp_kernel<5, 4>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns);
+  else if (u == 7 && tp == 4) hipLaunchKernelGGL((lgd_tp_kernel<7, 4>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns);
+  else if (u == 5 && tp == 2) hipLaunchKernelGGL((lgd_tp_kernel<5, 2>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns);
+  else if (u == 7 && tp == 2) hipLaunchKernelGGL((lgd_tp_kernel<7, 2>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 
 // chunk lengths compiled in; the host picks one that divides the rate's s100

@@ -93,6 +93,11 @@ class DeviceScanner:
         self._chk(self.L.lgd_execute(self.ctx, _stream_handle(stream)))
         return self
 
+    def join(self, stream=None):
+        """Order `stream` behind every scan enqueued so far ("overlap" 1: they may run on the
+        engine's own stream); needed before `stream` overwrites a PCM buffer being scanned."""
+        self._chk(self.L.lgd_join(self.ctx, _stream_handle(stream)))
+
     def fetch(self):
         res = (LgdTrackResult * max(1, self.n_tracks))()
         na = self.n_albums or 1
@@ -133,7 +138,12 @@ class DeviceScanner:
         n = C.c_uint32()
         self._chk(self.L.lgd_kernel_ms_stats(self.ctx, last_n, C.byref(a), C.byref(b), C.byref(c),
                                              C.byref(n)))
-        return dict(scan_mean_ms=a.value, scan_min_ms=b.value, total_mean_ms=c.value, n=n.value)
+        so_mean, so_min = C.c_float(), C.c_float()
+        self._chk(self.L.lgd_scan_only_ms_stats(self.ctx, last_n, C.byref(so_mean), C.byref(so_min)))
+        # scan_*: every kernel that reads PCM (scan kernels + the true-peak kernel behind them);
+        # scan_only_*: the scan kernels alone
+        return dict(scan_mean_ms=a.value, scan_min_ms=b.value, total_mean_ms=c.value, n=n.value,
+                    scan_only_mean_ms=so_mean.value, scan_only_min_ms=so_min.value)
 
     def plan_info(self):
         ns, nb, pb, wb = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()

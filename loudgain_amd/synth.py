@@ -29,7 +29,7 @@ def snap_s16_numpy(x):
     return (np.clip(np.round(x.astype(np.float64) * 32768.0), -32768, 32767) / 32768.0).astype(np.float32)
 
 
-def track_torch(frames, channels, rate, seed=0, step_s=10.0, device="cuda"):
+def track_torch(frames, channels, rate, seed=0, step_s=10.0, device="cuda", sine=True):
     """Same construction generated directly in HBM (torch's Philox stream; not
     bit-identical to track_numpy -- copy it back to the host to feed the oracle)."""
     import torch
@@ -45,8 +45,22 @@ def track_torch(frames, channels, rate, seed=0, step_s=10.0, device="cuda"):
         blk *= gains[idx][:, None]
         x[off:off + n] = blk
     t0, t1 = int(5 * rate), min(frames, int(6 * rate))
-    if t1 > t0:
+    if t1 > t0 and sine:
         n = torch.arange(t1 - t0, device=device, dtype=torch.float32)
         x[t0:t1] += (0.9 * torch.sin(2 * np.pi * n / 4.0 + np.pi / 4))[:, None]
+    x.mul_(32768.0).round_().clamp_(-32768, 32767).div_(32768.0)
+    return x
+
+
+def adversarial_torch(frames, channels, amplitude=0.8, device="cuda"):
+    """Worst case for the true-peak pruning: an fs/4 sine sampled on its peaks (0, A, 0, -A, ...
+    per channel, the second channel a quarter period later), so that the sample peak equals the
+    true peak in every window and no interpolator window can be skipped."""
+    import torch
+    n = torch.arange(frames, device=device, dtype=torch.int64)
+    x = torch.empty((frames, channels), dtype=torch.float32, device=device)
+    tab = torch.tensor([0.0, amplitude, 0.0, -amplitude], dtype=torch.float32, device=device)
+    for c in range(channels):
+        x[:, c] = tab[(n + c) % 4]
     x.mul_(32768.0).round_().clamp_(-32768, 32767).div_(32768.0)
     return x
