@@ -256,7 +256,7 @@ struct lgd_ctx {
     uint64_t lra_n = 0;
     float *d_peaks = nullptr;
     unsigned *d_hint = nullptr;     // per track and channel: peak found so far (LgdSeg::hint), 0 between scans
-    unsigned long long *d_tp_rows = nullptr;  // true-peak candidate rows, one per (tile, channel) (LgdSeg::tp_rows)
+    unsigned char *d_tp_rows = nullptr;  // chunk maxima, 1 KB per (group of 8 tiles, channel) (LgdSeg::tp_rows)
     LgdSeg *d_segs = nullptr;       // descriptors carry pointers into this set's E / peaks
     LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
     LgdRange *h_album_range = nullptr;  // pinned
@@ -598,8 +598,8 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
           const long long n_tiles = (sg.f_peak_end - sg.f0 + tile_f - 1) / tile_f;
           const long long rows = n_tiles * (long long)g_nch;
           if (rows > 0x7fffffffLL) return fail(LGD_EUNSUP, "track %u: segment too long", t);
-          sg.tp_rows = (unsigned long long *)(uintptr_t)c->total_tp_rows;
-          c->total_tp_rows += (uint64_t)rows;
+          sg.tp_rows = (void *)(uintptr_t)(c->total_tp_rows * 1024ull);  // byte offset, patched per work set
+          c->total_tp_rows += (uint64_t)((n_tiles + 7) / 8) * g_nch;        // groups of 8 tiles x channels
           g.rows_max = std::max(g.rows_max, (int)rows);
         }
         sg.peak_out = (float *)(uintptr_t)(m.peak_off + (long long)(sgi * 2ull * tr.channels));
@@ -660,7 +660,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if ((rc = ensure(&w.d_res, &w.cap_res, (size_t)n * LGR_STRIDE))) return rc;
     if ((rc = ensure(&w.d_peaks, &w.cap_peaks, c->total_peak_floats))) return rc;
     if ((rc = ensure(&w.d_segs, &w.cap_segs, c->segs.size()))) return rc;
-    if ((rc = ensure(&w.d_tp_rows, &w.cap_tp_rows, (size_t)c->total_tp_rows))) return rc;
+    if ((rc = ensure(&w.d_tp_rows, &w.cap_tp_rows, (size_t)c->total_tp_rows * 1024))) return rc;
     if ((rc = ensure(&w.d_hint, &w.cap_hint, (size_t)total_ch * LGD_HINT_STRIDE))) return rc;
     HIPCHK(hipMemset(w.d_hint, 0, std::max<size_t>(1, (size_t)total_ch * LGD_HINT_STRIDE) * sizeof(unsigned)));
     if ((rc = ensure(&w.d_ranges, &w.cap_ranges, n))) return rc;

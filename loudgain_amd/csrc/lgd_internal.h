@@ -20,9 +20,10 @@ struct LgdSeg {
   int ch0;               // first channel this workgroup handles (channel groups of
   int nch_total;         // streams with > 16 channels; otherwise 0 and the channel count)
   int pad;
-  unsigned long long *tp_rows;  // true-peak candidates of this segment: one 64-bit row per (tile k,
-                         // channel ch of this workgroup) at tp_rows[k * nch + ch], bit l = lane l's
-                         // chunk of the tile is flagged; null without interpolator
+  void *tp_rows;         // chunk maxima for lgd_tp_kernel: per group of 8 tiles and channel ch of this
+                         // workgroup 64 x 16 bytes at byte offset ((k / 8) * nch + ch) * 1024: lane l's
+                         // 8 bf16 values (largest |x| of its chunk in each tile, rounded up; a group of
+                         // n tiles fills the top n slots); null without interpolator
   unsigned *hint;        // [nch_total][LGD_HINT_STRIDE] (LGD_HINT_SLOTS used) per-channel peak found so far anywhere in the
                          // track (float bits, only ever a lower bound of the final peak; 16-B
                          // aligned): what the true-peak pruning of other segments may rely on;

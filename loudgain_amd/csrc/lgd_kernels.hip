@@ -42,6 +42,8 @@
 #define LGD_WAVE 64
 // entries (u16) of a wave's true-peak candidate queue in LDS, behind the staged tile
 #define LGD_TPQ_CAP 512
+// tiles whose chunk maxima travel in one 16-B store per lane (8 bf16 values)
+#define LGD_ROW_TILES 8
 
 // Wave priorities per section of a tile (measured, tools/prio_sweep.sh): the latency-bound
 // sections (staging, wave scan) first, and phase C above phase A -- the wave closer to
@@ -264,13 +266,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // segments published in sg.hint): outputs with L1 * max|x| <= pk_lb cannot raise
   // max(true peak, sample peak) -- the value ebur128_true_peak reports (E9) -- and are
   // not evaluated.  The result is bit-identical to evaluating everything.
-  float pk_lb = 0.f, pk_pub = 0.f;  // pk_pub: the largest peak this wave has published or seen published
-  // mc of lane 63 of the previous tile; +inf in front of the first tile (its frames were not looked at)
-  float mc_carry = __builtin_inff();
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 mc_rows = (u32x4)(0u);  // this lane's chunk maxima of the last 8 tiles (bf16, newest on top)
+  float pk_lb = 0.f, pk_pub = 0.f;  // pk_pub: the largest peak this wave has published or seen published
   u32x4 hint_nx[2] = {(u32x4)(0u), (u32x4)(0u)};  // slot loads in flight (taken one tile later)
-  const float tp_thr = F.tp_thr;
-  const int tp_prune = F.tp_prune;
   // Publishing: an atomic max on this workgroup's slot when the wave knows a peak 1 dB above
   // everything it has published or seen.  All slots of a channel share one 64-B line, i.e.
   // one memory-side atomic unit (~26 ns per atomic, measured: 2000 waves publishing their
@@ -405,11 +404,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       // would hoist a plain load out of the tile loop; the hand-placed wait is needed because
       // the compiler does not count asm loads (its own counted waits stay correct: these loads
       // are older than every load they wait for).)
-      // ("+v": the uses below must not be scheduled above this wait.  After a tile that ran
-      // phase C the youngest outstanding operation is that tile's row store -- issued last on
-      // purpose -- and need not be waited for: vmcnt(1).)
-      if (k > 0) asm volatile("s_waitcnt vmcnt(1)" : "+v"(hint_nx[0]), "+v"(hint_nx[1]) : : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(hint_nx[0]), "+v"(hint_nx[1]) : : "memory");
+      // ("+v": the uses below must not be scheduled above this wait)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(hint_nx[0]), "+v"(hint_nx[1]) : : "memory");
       {
         const unsigned a_ = max(max(hint_nx[0].x, hint_nx[0].y), max(hint_nx[0].z, hint_nx[0].w));
         const unsigned b_ = max(max(hint_nx[1].x, hint_nx[1].y), max(hint_nx[1].z, hint_nx[1].w));
@@ -421,6 +417,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
                    : "=&v"(hint_nx[0]), "=&v"(hint_nx[1]) : "v"(hint_base) : "memory");
     }
     if (k + 1 < n_main) LGD_PREFETCH(k + 1); else pf_valid = false;
+    // the chunk maxima of the last LGD_ROW_TILES tiles go out here
+    if constexpr (TP != 0) {
+      // (behind the loads just issued, and only one store per LGD_ROW_TILES tiles: a vector store
+      // costs the wave ~0.4 us here whatever its width -- one per tile was 10 % of the kernel)
+      if (k > 0 && (k & (LGD_ROW_TILES - 1)) == 0)
+        ((u32x4 LGD_GLOBAL *)sg.tp_rows)[((size_t)((k >> 3) - 1) * nch + ch) * LGD_WAVE + lane] = mc_rows;
+    }
     __builtin_amdgcn_s_setprio(LGD_PRIO_A);
 
     // this lane's chunk of this wave's channel: frames [tb + lane*C, +C), frame
@@ -642,25 +645,25 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 #undef LGD_STEP_PEAKS
 
     pk_s = fmaxf(pk_s, mc);
-    // ---- true peak: which chunks can matter (exact pruning, see pk_lb).  The interpolator
-    // outputs of a chunk read its own frames and the last HX of the chunk before it, so they
-    // are bounded by L1 * max(mc of this lane, mc of the previous lane); a chunk is flagged
-    // for lgd_tp_kernel when that can exceed the peak found so far.  One 64-bit row per wave
-    // and tile.  (Evaluating the interpolator here, with the tile still in LDS, was measured:
-    // loud passages cluster in time, the workgroup that owns one then runs long after the
-    // other 999 have finished, and the kernel takes as long as that workgroup.  The follow-up
-    // kernel spreads the flagged chunks over the whole GPU.)
+    // ---- true peak: hand this tile's chunk maxima to lgd_tp_kernel (one float per lane, one
+    // 256-B row per wave and tile); it decides with the channel's final peak which chunks'
+    // interpolator outputs can matter at all (exact pruning, see pk_lb).  (Evaluating the
+    // interpolator here, with the tile still in LDS, was measured: loud passages cluster in
+    // time, the workgroup that owns one then runs long after the other 999 have finished,
+    // and the kernel takes as long as that workgroup.  The follow-up kernel spreads the
+    // chunks that matter over the whole GPU.)
     if constexpr (TP != 0) {
       pk_lb = fmaxf(pk_lb, wave_max_f32_uniform(mc));
       LGD_PUBLISH(k);
-      const float thr = tp_prune ? pk_lb * tp_thr : -1.f;
-      const float mprev = __int_as_float(__builtin_amdgcn_update_dpp(
-          __float_as_int(mc_carry), __float_as_int(mc), 0x138, 0xf, 0xf, false));  // wave_shr:1
-      mc_carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mc), LGD_WAVE - 1));
-      const unsigned long long row = __ballot(fmaxf(mc, mprev) > thr);
-      // (the LAST vector-memory operation of the tile: see the vmcnt(1) at the top of the loop)
-      if (lane == 0)
-        ((unsigned long long LGD_GLOBAL *)sg.tp_rows)[(size_t)k * nch + ch] = row;
+      // this tile's chunk maximum, rounded UP to bf16 (a bound may only grow), enters the
+      // 8 x 16-bit shift register of the last tiles (stored every 8 tiles / behind the loop)
+      {
+        const unsigned code = (__float_as_uint(mc) + 0xFFFFu) >> 16;
+        mc_rows.x = __builtin_amdgcn_alignbit(mc_rows.y, mc_rows.x, 16);
+        mc_rows.y = __builtin_amdgcn_alignbit(mc_rows.z, mc_rows.y, 16);
+        mc_rows.z = __builtin_amdgcn_alignbit(mc_rows.w, mc_rows.z, 16);
+        mc_rows.w = (mc_rows.w >> 16) | (code << 16);
+      }
     }
 #undef LGD_X
 
@@ -702,6 +705,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     }
   }
 
+  if constexpr (TP != 0) {
+    if (n_main > 0)  // the last group: n_main mod 8 tiles (8 if 0), newest on top
+      ((u32x4 LGD_GLOBAL *)sg.tp_rows)[((size_t)((n_main - 1) >> 3) * nch + ch) * LGD_WAVE + lane] = mc_rows;
+  }
   {
     const float s = wave_max_f32(pk_s);
     if (lane == 0) {
@@ -722,9 +729,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 
 // --------------------------------------------------------- true-peak kernel ---
 // E4 (ebur128_check_true_peak / interp_process, reached from scan.c:448) for the chunks that
-// lgd_scan_kernel flagged.  Row r of a segment = (tile k = r / nch, channel r mod nch): a
-// 64-bit mask, bit l = "the C frames [tb + l C, + C) of the tile, tb = f0 + k * 64 C, may
-// hold a new peak".  One wave per row.  The row's flagged chunks are staged LGD_TP_GROUP at a
+// can still raise the peak.  Row r of a segment = (tile k = r / nch, channel r mod nch): 64
+// values, entry l = the largest |x| of lane l's chunk (rounded up to bf16), the C frames
+// [tb + l C, + C) of the tile, tb = f0 + k * 64 C.  One wave per row.  The row's flagged chunks are staged LGD_TP_GROUP at a
 // time -- each with the HX frames before it, coalesced loads that mostly hit L2 / Infinity
 // Cache, the scan kernel has just streamed those lines; the next group is in flight while one
 // is evaluated -- and a lane takes one (chunk, step) slot of the group: U output frames from
@@ -763,9 +770,6 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
   const int n_main = (int)((sg.f_peak_end - sg.f0 + tile_f - 1) / tile_f);
   const int row = blockIdx.y * LGD_TP_WAVES + wave;
   if (row >= n_main * nch) return;  // wave-uniform
-  const unsigned long long mask = ((const unsigned long long LGD_GLOBAL *)sg.tp_rows)[row];
-  const int n_chunks = __popcll(mask);
-  if (n_chunks == 0) return;
   const int k = row / nch, ch = row - k * nch;
   const int nch_tot = sg.nch_total ? sg.nch_total : nch;
   const int chan = sg.ch0 + ch;  // channel of the stream (channel groups of wide streams: ch0 > 0)
@@ -793,6 +797,40 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
     for (int i = 0; i < LGD_HINT_SLOTS; ++i) m = max(m, h[i]);
     thr = __int_as_float(m) * F0->tp_thr;
   }
+  // Which chunks can matter: the interpolator outputs of lane l's chunk read its own frames and
+  // the last HX of the chunk before it, so they are bounded by L1 * max(mc[l], mc[l - 1]) (mc =
+  // the chunk maxima the scan kernel stored; the chunk before lane 0 is lane 63 of the previous
+  // tile's row -- in front of a segment's first tile nothing is known: +inf).
+  unsigned long long mask;
+  {
+    // tile k's maxima: group g = k / 8, 16-bit slot `slot` of every lane's 16 bytes (the scan
+    // kernel shifts new tiles in at the top: a group of n tiles fills slots 8 - n .. 7)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 LGD_GLOBAL *rows = (const u32x4 LGD_GLOBAL *)sg.tp_rows;
+    const int g = k >> 3, g_last = (n_main - 1) >> 3;
+    const int n_in = g == g_last ? ((n_main - 1) & 7) + 1 : 8;
+    const int slot = 8 - n_in + (k & 7);
+    const u32x4 mine = rows[((size_t)g * nch + ch) * LGD_WAVE + lane];
+    auto code_at = [](const u32x4 v, const int sl) -> float {  // (sl is wave-uniform)
+      const unsigned w = (sl >> 1) == 0 ? v.x : ((sl >> 1) == 1 ? v.y : ((sl >> 1) == 2 ? v.z : v.w));
+      return __uint_as_float(((sl & 1) ? (w >> 16) : (w & 0xffffu)) << 16);
+    };
+    const float mc = code_at(mine, slot);
+    float carry = __builtin_inff();  // in front of a segment's first tile nothing is known
+    if (k > 0) {
+      if ((k & 7) != 0) {
+        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(code_at(mine, slot - 1)), LGD_WAVE - 1));
+      } else {
+        const u32x4 prev = rows[((size_t)(g - 1) * nch + ch) * LGD_WAVE + (LGD_WAVE - 1)];
+        carry = code_at(prev, 7);
+      }
+    }
+    const float mprev = __int_as_float(__builtin_amdgcn_update_dpp(
+        __float_as_int(carry), __float_as_int(mc), 0x138, 0xf, 0xf, false));  // wave_shr:1
+    mask = __ballot(fmaxf(mc, mprev) > thr);
+  }
+  const int n_chunks = __popcll(mask);
+  if (n_chunks == 0) return;
   // entry o of the table: the o-th set bit of the mask
   if ((mask >> lane) & 1ull)
     chunk_of[wave][__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
