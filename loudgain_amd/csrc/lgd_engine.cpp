@@ -24,15 +24,16 @@ extern "C" const int lgd_chunk_table[];
 extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic);
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, const LgdSeg *segs,
                                       int n_seg, const LgdFilt *F, hipStream_t s);
+extern "C" hipError_t lgd_launch_peak_reduce(const LgdTrackMeta *meta, int n_tracks, const float *peaks,
+                                             float *hint, hipStream_t s);
 extern "C" hipError_t lgd_launch_tp(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
                                     int rows_max, const LgdFilt *F, hipStream_t s);
 extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_slices,
                                                 const LgdTrackMeta *meta, int n_tracks,
                                                 const double *E, double *Z, double *st,
                                                 const float *peaks, double *p1, double *p2,
-                                                double *pmax_s, double *res, unsigned *hint,
-                                                double abs_gate, double rel_factor, int do_tp,
-                                                hipStream_t s);
+                                                double *pmax_s, double *res, double abs_gate,
+                                                double rel_factor, int do_tp, hipStream_t s);
 extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
                                      double minus20, hipStream_t s);
 extern "C" hipError_t lgd_launch_album_part1(const double *res, const LgdAlbumMeta *albums,
@@ -189,7 +190,7 @@ static void design_interp(int factor, float tp[36]) {
   }
 }
 
-// Pruning bound of the interpolator (lgd_scan_kernel, pk_lb): every output of a window is at
+// Pruning bound of the interpolator (lgd_tp_kernel): every output of a window is at
 // most L1 * max|x| of it, L1 = the largest sum of |taps| of a non-trivial phase (4x: 1.8642
 // for phase 2, 1.6312 for phases 1 / 3; 2x: 2.3068).  The kernel evaluates the taps in fp32
 // through sums and differences of mirrored samples: ~14 roundings of 2^-24 each on
@@ -255,7 +256,7 @@ struct lgd_ctx {
     const double *lra_base = nullptr;  // short-term list of the album (set by stage 2)
     uint64_t lra_n = 0;
     float *d_peaks = nullptr;
-    unsigned *d_hint = nullptr;     // per track and channel: peak found so far (LgdSeg::hint), 0 between scans
+    float *d_hint = nullptr;        // per track and channel: sample peak of the whole track (LgdSeg::hint)
     unsigned char *d_tp_rows = nullptr;  // chunk maxima, 1 KB per (group of 8 tiles, channel) (LgdSeg::tp_rows)
     LgdSeg *d_segs = nullptr;       // descriptors carry pointers into this set's E / peaks
     LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
@@ -591,11 +592,12 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         sg.e_ch_stride = m.n_sb;
         sg.ch0 = (int)ch0;
         sg.nch_total = (int)tr.channels;
-        sg.pad = 0;
-        sg.hint = (unsigned *)(uintptr_t)m.hint_off;
+        sg.n_tiles = (int)((sg.f_peak_end - sg.f0 + tile_f - 1) / tile_f);
+        sg.n_frames = (long long)tr.frames;
+        sg.hint = (float *)(uintptr_t)m.hint_off;
         sg.tp_rows = nullptr;
         if (g.tp) {  // one row of candidate bits per tile and channel of this workgroup
-          const long long n_tiles = (sg.f_peak_end - sg.f0 + tile_f - 1) / tile_f;
+          const long long n_tiles = sg.n_tiles;
           const long long rows = n_tiles * (long long)g_nch;
           if (rows > 0x7fffffffLL) return fail(LGD_EUNSUP, "track %u: segment too long", t);
           sg.tp_rows = (void *)(uintptr_t)(c->total_tp_rows * 1024ull);  // byte offset, patched per work set
@@ -661,15 +663,14 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if ((rc = ensure(&w.d_peaks, &w.cap_peaks, c->total_peak_floats))) return rc;
     if ((rc = ensure(&w.d_segs, &w.cap_segs, c->segs.size()))) return rc;
     if ((rc = ensure(&w.d_tp_rows, &w.cap_tp_rows, (size_t)c->total_tp_rows * 1024))) return rc;
-    if ((rc = ensure(&w.d_hint, &w.cap_hint, (size_t)total_ch * LGD_HINT_STRIDE))) return rc;
-    HIPCHK(hipMemset(w.d_hint, 0, std::max<size_t>(1, (size_t)total_ch * LGD_HINT_STRIDE) * sizeof(unsigned)));
+    if ((rc = ensure(&w.d_hint, &w.cap_hint, (size_t)total_ch))) return rc;
     if ((rc = ensure(&w.d_ranges, &w.cap_ranges, n))) return rc;
     // the host descriptors hold offsets; each set gets its own pointers
     std::vector<LgdSeg> segs(c->segs);
     for (LgdSeg &sg : segs) {
       sg.e_out = w.d_E + (uintptr_t)sg.e_out;
       sg.peak_out = w.d_peaks + (uintptr_t)sg.peak_out;
-      sg.hint = w.d_hint + (uintptr_t)sg.hint * LGD_HINT_STRIDE;
+      sg.hint = w.d_hint + (uintptr_t)sg.hint;
       // (sg.tp_rows holds an element offset; only interpolating groups use it)
       sg.tp_rows = w.d_tp_rows + (uintptr_t)sg.tp_rows;
     }
@@ -807,8 +808,10 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
                            (int)g.seg_count, c->d_filt + gi, s));
   }
   if (c->p_timing) HIPCHK(hipEventRecord(ev[3], s));
-  // the interpolator over the windows the scan kernels flagged (every channel's peak hints are
-  // final once all scan kernels of the plan are done: a track's channels share one launch)
+  // per-channel sample peaks of the whole tracks, then the interpolator over the chunks that
+  // can exceed them
+  if (c->flags & LGD_FLAG_TRUE_PEAK)
+    HIPCHK(lgd_launch_peak_reduce(c->d_meta, n, w.d_peaks, w.d_hint, s));
   for (size_t gi = 0; gi < c->groups.size(); ++gi) {
     const Group &g = c->groups[gi];
     HIPCHK(lgd_launch_tp(g.chunk, (int)g.nch, g.tp, w.d_segs + g.seg_begin, (int)g.seg_count, g.rows_max,
@@ -816,8 +819,8 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   }
   if (c->p_timing) HIPCHK(hipEventRecord(ev[1], s));
   HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, w.d_E, w.d_Z,
-                                   w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_pmax, w.d_res, w.d_hint,
-                                   c->abs_gate, c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
+                                   w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_pmax, w.d_res, c->abs_gate,
+                                   c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
   HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, s));
   c->executed = true;
   if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))

@@ -201,8 +201,7 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass2(
 __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
     const LgdTrackMeta *__restrict__ meta, const double *__restrict__ p1,
     const double *__restrict__ p2, const double *__restrict__ pmax_s,
-    const float *__restrict__ peaks, double *__restrict__ res_all, unsigned *__restrict__ hint,
-    double rel_factor, int do_tp) {
+    const float *__restrict__ peaks, double *__restrict__ res_all, double rel_factor, int do_tp) {
   LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
   const LgdTrackMeta m = meta[blockIdx.x];
@@ -235,10 +234,6 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
   }
   sp = block_max_f64<LGD_EPI_NT>(sp, sh);
   tp = block_max_f64<LGD_EPI_NT>(tp, sh);
-  // the scan kernels of this execute are done with the track's peak hints: clear them for
-  // the next scan into this work set (they must never outlive the PCM they were taken from)
-  for (int i = tid; i < m.nch * LGD_HINT_STRIDE; i += LGD_EPI_NT)
-    hint[(size_t)m.hint_off * LGD_HINT_STRIDE + i] = 0u;
   if (tid == 0) {
     double thr = 0.0;
     if (n_abs > 0.0) {
@@ -251,7 +246,7 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
     res[LGR_PEAK] = do_tp ? fmax(sp, tp) : sp;
     res[LGR_SPEAK] = sp;
     // ebur128_true_peak's value: max(interpolated, sample).  (The scan kernel evaluates only
-    // the interpolator windows that can exceed the peak already found, so its interpolated
+    // the interpolator outputs that can exceed the track's sample peak, so the interpolated
     // maximum alone is exact only where it is the larger of the two.)
     res[LGR_TPEAK] = do_tp ? fmax(sp, tp) : 0.0;
     res[LGR_THR] = thr;
@@ -468,9 +463,8 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
                                                 const LgdTrackMeta *meta, int n_tracks,
                                                 const double *E, double *Z, double *st,
                                                 const float *peaks, double *p1, double *p2,
-                                                double *pmax_s, double *res, unsigned *hint,
-                                                double abs_gate, double rel_factor, int do_tp,
-                                                hipStream_t s) {
+                                                double *pmax_s, double *res, double abs_gate,
+                                                double rel_factor, int do_tp, hipStream_t s) {
   if (n_tracks <= 0) return hipSuccess;
   if (n_slices > 0) {
     hipLaunchKernelGGL(lgd_gate_pass1, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, E, Z, st,
@@ -479,7 +473,7 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
                        (const double *)nullptr, 0, 0LL, abs_gate, rel_factor);
   }
   hipLaunchKernelGGL(lgd_track_final, dim3(n_tracks), dim3(LGD_EPI_NT), 0, s, meta, p1, p2, pmax_s, peaks,
-                     res, hint, rel_factor, do_tp);
+                     res, rel_factor, do_tp);
   return hipGetLastError();
 }
 

@@ -19,15 +19,14 @@ struct LgdSeg {
   int e_ch_stride;       // whole sub-blocks of the track (channel stride in E)
   int ch0;               // first channel this workgroup handles (channel groups of
   int nch_total;         // streams with > 16 channels; otherwise 0 and the channel count)
-  int pad;
+  int n_tiles;           // tiles of 64 * chunk frames that cover [f0, f_peak_end)
+  long long n_frames;    // frames of the whole track (n_floats / channels of the stream)
   void *tp_rows;         // chunk maxima for lgd_tp_kernel: per group of 8 tiles and channel ch of this
                          // workgroup 64 x 16 bytes at byte offset ((k / 8) * nch + ch) * 1024: lane l's
                          // 8 bf16 values (largest |x| of its chunk in each tile, rounded up; a group of
                          // n tiles fills the top n slots); null without interpolator
-  unsigned *hint;        // [nch_total][LGD_HINT_STRIDE] (LGD_HINT_SLOTS used) per-channel peak found so far anywhere in the
-                         // track (float bits, only ever a lower bound of the final peak; 16-B
-                         // aligned): what the true-peak pruning of other segments may rely on;
-                         // zeroed between scans
+  float *hint;           // [nch_total] this track's per-channel sample peak (lgd_peak_reduce_kernel): the
+                         // bound lgd_tp_kernel prunes with
 };
 
 // Per-(rate, chunk) constants, passed by value as a kernel argument.
@@ -63,10 +62,6 @@ constexpr int lgd_unroll(int C) {
 // blocks, one workgroup per slice (fixed size -> fixed, reproducible summation
 // tree, independent of how the scan kernel was segmented).
 #define LGD_SLICE 1024
-// words per channel of the peak-hint array (one per XCD: blockIdx mod 8)
-#define LGD_HINT_SLOTS 8
-// words from one channel's slots to the next channel's: a 64-B line per channel
-#define LGD_HINT_STRIDE 16
 
 struct LgdSlice {
   int track;
@@ -87,8 +82,7 @@ struct LgdTrackMeta {
   int slice_off;      // first epilogue slice of this track
   int n_slices;       // ceil((n_sb - 3) / LGD_SLICE), 0 if n_sb < 4
   int album;          // album of this track (albums are runs of consecutive tracks)
-  int hint_off;       // first of this track's nch channels in the peak-hint array (LgdSeg::hint;
-                      // LGD_HINT_STRIDE words per channel)
+  int hint_off;       // first of this track's nch channels in the per-channel peak array (LgdSeg::hint)
   int pad;
 };
 

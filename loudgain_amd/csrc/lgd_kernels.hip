@@ -160,7 +160,8 @@ extern "C" hipError_t lgd_debug_counters(unsigned long long *out, int reset) {
 // C   frames per lane (divides the 100 ms sub-block length of the rate)
 // G   channels == waves per workgroup; 0 = run-time value (frame stride in LDS
 //     is then a register instead of an immediate)
-// TP  0 = no interpolator (>= 192 kHz or disabled), 4 = 4x, 2 = 2x
+// TP  0 = no interpolator (>= 192 kHz or disabled); otherwise the chunk maxima of every tile
+//     are recorded for lgd_tp_kernel (instantiated as 4 for both the 4x and the 2x interpolator)
 // LDS layout of a staged tile.
 //  G == 0 (run-time channel count): interleaved as in memory, frame stride nch.
 //  G >= 1 (compiled for 1 .. 6 and 8): PLANAR, one plane per channel, and every lane's C-frame chunk is
@@ -182,10 +183,7 @@ struct LdsLayout {
 
 template <int C, int TP>
 struct ScanCfg {
-  static constexpr int HALO = (TP == 2) ? 24 : 12;     // frames kept before the tile
-  static constexpr int NTAP = (TP == 2) ? 24 : 12;     // taps per non-trivial phase
-  static constexpr int NPH = (TP == 4) ? 3 : (TP == 2 ? 1 : 0);
-  static constexpr int HX = (TP == 0) ? 0 : (NTAP - 1);  // history frames the FIR needs
+  static constexpr int HALO = 12;  // frames kept before the tile (the filter needs 2)
   static constexpr int TILE_F = LGD_WAVE * C;
   // 16-B vectors per thread and tile: ceil(((TILE_F + HALO) nch + 4) / 4 / (64 nch))
   static constexpr int NV = (16 * C + HALO / 4 + 1 + 63) / 64;
@@ -196,14 +194,12 @@ struct ScanCfg {
 // (launch bounds: G waves per workgroup, >= 2 waves per SIMD wanted -> <= 256 VGPRs;
 // the run-time-G variant must fit 16 waves -> <= 128 VGPRs, so the host gives it
 // short chunks)
-// The interpolator variants are pinned to exactly 2 waves per SIMD: left alone,
-// hipcc aims for 3 and spills the FIR window to scratch.
 // WIDE (run-time-G kernel only): up to 16 waves per workgroup -> <= 128 VGPRs;
 // otherwise up to 8 waves (<= 256 VGPRs, no spills).
 template <int C, int G, int TP, bool WIDE = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
                                                       G ? LGD_WAVE * G : (WIDE ? 1024 : 512)),
-                          amdgpu_waves_per_eu(G ? (G > 2 ? 3 : 2) : (WIDE ? 4 : 2), (G && G <= 2 && TP) ? 2 : 4))) void lgd_scan_kernel(
+                          amdgpu_waves_per_eu(G ? (G > 2 ? 3 : 2) : (WIDE ? 4 : 2), 4))) void lgd_scan_kernel(
     const LgdSeg *__restrict__ segs, const LgdFilt *__restrict__ Fg, const int nch_rt) {
   using K = ScanCfg<C, TP>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -222,7 +218,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   const int nthreads = LGD_WAVE * nch;
   const LgdSeg sg = segs[blockIdx.x];
   const int shift = (G == 0 && sg.nch_total != (G ? G : nch_rt)) ? 0 : (int)((sg.f0 * nch) & 3);
-  const long long n_frames = sg.n_floats / (G ? G : sg.nch_total);
+  const long long n_frames = sg.n_frames;
   const int nvec = ((K::TILE_F + K::HALO) * nch + 4) >> 2;  // 16-B vectors per tile
   // frame slot of tile frame -HALO inside a plane
   using LL = LdsLayout<C, G>;
@@ -260,38 +256,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   int cur = 0;            // sub-block (relative to the segment) being summed
   int cur_q = 0;          // chunk index (relative to f0) where `cur` starts
   float pk_s = 0.f;
-  // True-peak pruning (exact).  An interpolated output is sum_k c_k x[n-k], so it cannot exceed
-  // L1 * (largest |x| it reads), L1 = largest sum |c_k| of a phase.  pk_lb is a peak this
-  // channel of this track is already known to reach (own samples so far and what other
-  // segments published in sg.hint): outputs with L1 * max|x| <= pk_lb cannot raise
-  // max(true peak, sample peak) -- the value ebur128_true_peak reports (E9) -- and are
-  // not evaluated.  The result is bit-identical to evaluating everything.
+  // (true peak: this kernel only records every chunk's largest |x|; lgd_tp_kernel decides from
+  // them which interpolator outputs can matter and evaluates those)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   u32x4 mc_rows = (u32x4)(0u);  // this lane's chunk maxima of the last 8 tiles (bf16, newest on top)
-  float pk_lb = 0.f, pk_pub = 0.f;  // pk_pub: the largest peak this wave has published or seen published
-  u32x4 hint_nx[2] = {(u32x4)(0u), (u32x4)(0u)};  // slot loads in flight (taken one tile later)
-  // Publishing: an atomic max on this workgroup's slot when the wave knows a peak 1 dB above
-  // everything it has published or seen.  All slots of a channel share one 64-B line, i.e.
-  // one memory-side atomic unit (~26 ns per atomic, measured: 2000 waves publishing their
-  // first tile at once stalled every one of them ~50 us at its next vmcnt wait).  So in its
-  // first two tiles only every 16th workgroup publishes; the others have polled those
-  // values by their third tile and publish only what exceeds them.
-  const int k_first = -sg.n_warm_tiles;
-  const bool early_pub = (blockIdx.x & 15) == 0;
-#define LGD_PUBLISH(k_)                                                                         \
-  do {                                                                                          \
-    if (pk_lb > pk_pub * 1.122f && (early_pub || (k_) >= k_first + 2)) { /* wave-uniform */     \
-      if (lane == 0)                                                                            \
-        (void)__hip_atomic_fetch_max(hint_base + (blockIdx.x & (LGD_HINT_SLOTS - 1)),           \
-                                     (unsigned)__float_as_int(pk_lb), __ATOMIC_RELAXED,         \
-                                     __HIP_MEMORY_SCOPE_AGENT);                                 \
-      pk_pub = pk_lb;                                                                           \
-    }                                                                                           \
-  } while (0)
-  unsigned LGD_GLOBAL *const hint_base =
-      (unsigned LGD_GLOBAL *)sg.hint + (size_t)((G ? 0 : sg.ch0) + ch) * LGD_HINT_STRIDE;
 
-  const int n_main = (int)((sg.f_peak_end - sg.f0 + K::TILE_F - 1) / K::TILE_F);
+  const int n_main = sg.n_tiles;
 
   // ---- tile staging: coalesced 16-B loads -> registers -> LDS.  The NEXT tile's
   // loads are issued before the current tile is computed (software prefetch,
@@ -387,35 +357,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     }
 #undef LGD_STORE_VEC
     __syncthreads();
-    // What the other segments of this channel have found so far.  The value asked for during
-    // the PREVIOUS tile is taken here, where no load is outstanding (the staging above has
-    // consumed them all), and the next one is requested before the next tile's loads: no
-    // wait on it can ever wait for those.
-    if constexpr (TP != 0) {
-      // (One polled word per channel does not work: an agent-scope atomic load of a word that
-      // every wave of the track polls is served by one memory channel at ~13 ns apiece --
-      // 76 000 of them per C3 launch took longer than the scan itself -- and atomics on it
-      // serialise the same way, each wave then waiting for its own at the next staging.  Hence:
-      // LGD_HINT_SLOTS words per channel, a wave publishes to the slot of its workgroup
-      // (blockIdx mod 8: workgroups that share an XCD share a slot), only when it knows a peak
-      // 1 dB above everything it has seen, and polls with PLAIN cached loads.  Cached copies go
-      // stale, but the tile streams evict them within a tile or two (L1 32 KB per CU, L2 4 MB
-      // per XCD) and any older value is still a valid lower bound.  Inline asm, or the optimiser
-      // would hoist a plain load out of the tile loop; the hand-placed wait is needed because
-      // the compiler does not count asm loads (its own counted waits stay correct: these loads
-      // are older than every load they wait for).)
-      // ("+v": the uses below must not be scheduled above this wait)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(hint_nx[0]), "+v"(hint_nx[1]) : : "memory");
-      {
-        const unsigned a_ = max(max(hint_nx[0].x, hint_nx[0].y), max(hint_nx[0].z, hint_nx[0].w));
-        const unsigned b_ = max(max(hint_nx[1].x, hint_nx[1].y), max(hint_nx[1].z, hint_nx[1].w));
-        const float seen = __int_as_float(__builtin_amdgcn_readfirstlane((int)max(a_, b_)));
-        pk_lb = fmaxf(pk_lb, seen);
-        pk_pub = fmaxf(pk_pub, seen);
-      }
-      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
-                   : "=&v"(hint_nx[0]), "=&v"(hint_nx[1]) : "v"(hint_base) : "memory");
-    }
     if (k + 1 < n_main) LGD_PREFETCH(k + 1); else pf_valid = false;
     // the chunk maxima of the last LGD_ROW_TILES tiles go out here
     if constexpr (TP != 0) {
@@ -454,7 +395,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       double z[4];
       {
         double qv[4] = {0.0, 0.0, 0.0, 0.0}, pv[4] = {0.0, 0.0, 0.0, 0.0};
-        float ma = 0.f;  // warm-up tiles only: largest |x| (the first peak estimate to publish)
         // LDS reads run one step ahead of the arithmetic (software pipeline)
         float xa[U];
 #pragma unroll
@@ -496,14 +436,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         z[1] = fma(g1[1], dw1, fma(g0[1], dw0, alpha * fma(-beta, q2, q1)));
         z[2] = fma(g1[2], dw1, fma(g0[2], dw0, gamma_ * p1));
         z[3] = fma(g1[3], dw1, fma(g0[3], dw0, gamma_ * p2));
-        if constexpr (TP != 0) {
-          if (k < 0) {  // (a second pass over the chunk: two tiles per segment only)
-#pragma unroll
-            for (int j = 0; j < C; ++j) ma = fmaxf(ma, fabsf(LGD_X(j)));
-            pk_lb = fmaxf(pk_lb, wave_max_f32_uniform(ma));
-            LGD_PUBLISH(k);
-          }
-        }
       }
 
       // (latency-bound section: issue priority over the SIMD's other wave, which is most
@@ -647,14 +579,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     pk_s = fmaxf(pk_s, mc);
     // ---- true peak: hand this tile's chunk maxima to lgd_tp_kernel (one float per lane, one
     // 256-B row per wave and tile); it decides with the channel's final peak which chunks'
-    // interpolator outputs can matter at all (exact pruning, see pk_lb).  (Evaluating the
+    // interpolator outputs can matter at all (exact pruning).  (Evaluating the
     // interpolator here, with the tile still in LDS, was measured: loud passages cluster in
     // time, the workgroup that owns one then runs long after the other 999 have finished,
     // and the kernel takes as long as that workgroup.  The follow-up kernel spreads the
     // chunks that matter over the whole GPU.)
     if constexpr (TP != 0) {
-      pk_lb = fmaxf(pk_lb, wave_max_f32_uniform(mc));
-      LGD_PUBLISH(k);
       // this tile's chunk maximum, rounded UP to bf16 (a bound may only grow), enters the
       // 8 x 16-bit shift register of the last tiles (stored every 8 tiles / behind the loop)
       {
@@ -715,16 +645,41 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       ((float LGD_GLOBAL *)sg.peak_out)[ch0 + ch] = s;
       // the interpolated peak of the segment: lgd_tp_kernel raises it (atomic max on the bits)
       ((float LGD_GLOBAL *)sg.peak_out)[nch_tot + ch0 + ch] = 0.f;
-      if constexpr (TP != 0) {
-        // everything this wave knows, without the 1 dB hysteresis: lgd_tp_kernel prunes with it
-        if (fmaxf(pk_lb, s) > pk_pub)
-          (void)__hip_atomic_fetch_max(hint_base + (blockIdx.x & (LGD_HINT_SLOTS - 1)),
-                                       (unsigned)__float_as_int(fmaxf(pk_lb, s)), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
   }
 #undef F
+}
+
+// ------------------------------------------------------- track sample peaks ---
+// Per track and channel: the largest sample peak any segment found (the scan kernels'
+// peak_out partials) -> hint[hint_off + ch], the bound lgd_tp_kernel prunes with.  One
+// workgroup per track.  (An exchange between the running scan workgroups was measured
+// instead -- polled hint words, atomic-max publishing: every variant cost the scan kernel
+// 5-25 %, because all waves of a track hammer one memory channel.)
+__global__ __launch_bounds__(256) void lgd_peak_reduce_kernel(const LgdTrackMeta *__restrict__ meta,
+                                                             const float *__restrict__ peaks,
+                                                             float *__restrict__ hint) {
+  __shared__ float sh[256];
+  const LgdTrackMeta m = meta[blockIdx.x];
+  for (int ch = 0; ch < m.nch; ++ch) {
+    float v = 0.f;
+    for (int sgi = threadIdx.x; sgi < m.n_seg; sgi += 256)
+      v = fmaxf(v, peaks[m.peak_off + (size_t)sgi * 2 * m.nch + ch]);
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+      if ((int)threadIdx.x < d) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + d]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) hint[m.hint_off + ch] = sh[0];
+    __syncthreads();
+  }
+}
+extern "C" hipError_t lgd_launch_peak_reduce(const LgdTrackMeta *meta, int n_tracks, const float *peaks,
+                                             float *hint, hipStream_t s) {
+  if (n_tracks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lgd_peak_reduce_kernel, dim3(n_tracks), dim3(256), 0, s, meta, peaks, hint);
+  return hipGetLastError();
 }
 
 // --------------------------------------------------------- true-peak kernel ---
@@ -755,7 +710,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 template <int U, int TP>
 __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
     const LgdSeg *__restrict__ segs, const LgdFilt *__restrict__ Fg, const int C, const int nch,
-    const unsigned magic_ch, const unsigned magic_ns) {
+    const unsigned magic_ch, const unsigned magic_ns, const unsigned magic_nch) {
   constexpr int HX = (TP == 2) ? 23 : 11;
   // per wave: the ids of the row's flagged chunks, and the staged frames of one group of them
   // (chunk c of the group at [c * (C + HX), + C + HX): its HX frames of history, then its own)
@@ -767,13 +722,15 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const LgdSeg sg = segs[blockIdx.x];
   const long long tile_f = (long long)LGD_WAVE * C;
-  const int n_main = (int)((sg.f_peak_end - sg.f0 + tile_f - 1) / tile_f);
+  const int n_main = sg.n_tiles;
   const int row = blockIdx.y * LGD_TP_WAVES + wave;
   if (row >= n_main * nch) return;  // wave-uniform
-  const int k = row / nch, ch = row - k * nch;
+  // (the way to the early exit below is kept short: every row of the plan comes through here)
+  const int k = magic_nch ? (int)__umulhi((unsigned)row, magic_nch) : row;  // row / nch
+  const int ch = row - k * nch;
   const int nch_tot = sg.nch_total ? sg.nch_total : nch;
   const int chan = sg.ch0 + ch;  // channel of the stream (channel groups of wide streams: ch0 > 0)
-  const long long n_frames = sg.n_floats / nch_tot;
+  const long long n_frames = sg.n_frames;
   const long long tb = sg.f0 + (long long)k * tile_f;
   const gflt_ptr pcm = (gflt_ptr)sg.pcm + chan;
   const int CH = C + HX, NSTEP = C / U;
@@ -788,15 +745,13 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
   for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpb[i] = F0->tp[12 + i];
   (void)tpa; (void)tpb; (void)tpsd;
 
-  // the channel's peak as the scan kernels left it (LGD_HINT_SLOTS words, all final by now)
+  // Exact pruning: an interpolated output is sum_k c_k x[n-k], so it cannot exceed L1 * (largest
+  // |x| it reads), L1 = largest sum |c_k| of a phase.  sg.hint holds this channel's sample peak
+  // over the whole track (lgd_peak_reduce): outputs with L1 * max|x| <= it cannot raise
+  // max(true peak, sample peak) -- the value ebur128_true_peak reports (E9) -- and are not
+  // evaluated.  The result is bit-identical to evaluating everything (tp_prune 0: thr < 0).
   float thr = -1.f;
-  if (F0->tp_prune) {
-    const unsigned LGD_GLOBAL *h = (const unsigned LGD_GLOBAL *)sg.hint + (size_t)chan * LGD_HINT_STRIDE;
-    unsigned m = 0u;
-#pragma unroll
-    for (int i = 0; i < LGD_HINT_SLOTS; ++i) m = max(m, h[i]);
-    thr = __int_as_float(m) * F0->tp_thr;
-  }
+  if (F0->tp_prune) thr = ((const float LGD_GLOBAL *)sg.hint)[chan] * F0->tp_thr;
   // Which chunks can matter: the interpolator outputs of lane l's chunk read its own frames and
   // the last HX of the chunk before it, so they are bounded by L1 * max(mc[l], mc[l - 1]) (mc =
   // the chunk maxima the scan kernel stored; the chunk before lane 0 is lane 63 of the previous
@@ -944,7 +899,8 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
 // LDS bytes one workgroup needs (also used by the host-side planner); mirrors
 // LdsLayout / PLANE in the kernel.  generic != 0: the run-time-channel-count kernel.
 extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
-  const int halo = tp == 2 ? 24 : 12;
+  const int halo = 12;
+  (void)tp;
   const bool planar = !generic;
   const size_t queue = 0;
   if (planar) {
@@ -985,7 +941,7 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
                                 hipStream_t s) {
   if (nch == 1) {
     if (tp == 4) return launch_scan_t<C, 1, 4>(segs, n_seg, F, nch, s);
-    if (tp == 2) return launch_scan_t<C, 1, 2>(segs, n_seg, F, nch, s);
+    if (tp == 2) return launch_scan_t<C, 1, 4>(segs, n_seg, F, nch, s);
     return launch_scan_t<C, 1, 0>(segs, n_seg, F, nch, s);
   }
   if (nch > 2) {  // 3 .. 6 or 8 planes per workgroup (2.1, quad, 5.0, 5.1, 7.1): the short chunks only
@@ -993,7 +949,7 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
 #define LGD_DISPATCH_G(g_)                                                              \
       if (nch == g_) {                                                                  \
         if (tp == 4) return launch_scan_t<C, g_, 4>(segs, n_seg, F, nch, s);            \
-        if (tp == 2) return launch_scan_t<C, g_, 2>(segs, n_seg, F, nch, s);            \
+        if (tp == 2) return launch_scan_t<C, g_, 4>(segs, n_seg, F, nch, s);            \
         return launch_scan_t<C, g_, 0>(segs, n_seg, F, nch, s);                         \
       }
       LGD_DISPATCH_G(3) LGD_DISPATCH_G(4) LGD_DISPATCH_G(5) LGD_DISPATCH_G(6) LGD_DISPATCH_G(8)
@@ -1002,7 +958,7 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
     return hipErrorInvalidValue;
   }
   if (tp == 4) return launch_scan_t<C, 2, 4>(segs, n_seg, F, nch, s);
-  if (tp == 2) return launch_scan_t<C, 2, 2>(segs, n_seg, F, nch, s);
+  if (tp == 2) return launch_scan_t<C, 2, 4>(segs, n_seg, F, nch, s);
   return launch_scan_t<C, 2, 0>(segs, n_seg, F, nch, s);
 }
 
@@ -1021,10 +977,14 @@ extern "C" hipError_t lgd_launch_tp(int chunk, int nch, int tp, const LgdSeg *se
     if (((x * magic_ch) >> 20) != x / ch_len) return hipErrorInvalidValue;
   for (unsigned x = 0; x < LGD_TP_GROUP * nstep + LGD_WAVE; ++x)
     if (((x * magic_ns) >> 20) != x / nstep) return hipErrorInvalidValue;
-  if (u == 5 && tp == 4) hipLaunchKernelGGL((lgd_tp_kernel<5, 4>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns);
-  else if (u == 7 && tp == 4) hipLaunchKernelGGL((lgd_tp_kernel<7, 4>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns);
-  else if (u == 5 && tp == 2) hipLaunchKernelGGL((lgd_tp_kernel<5, 2>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns);
-  else if (u == 7 && tp == 2) hipLaunchKernelGGL((lgd_tp_kernel<7, 2>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns);
+  // row / nch == umulhi(row, magic_nch) for row * (magic_nch * nch - 2^32) < 2^32; the error
+  // term is < nch <= 64, so every row below 2^26 divides exactly
+  const unsigned magic_nch = nch == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)nch - 1) / (unsigned)nch);  // 0: k = row
+  if ((long long)rows_max >= (1ll << 26)) return hipErrorInvalidValue;
+  if (u == 5 && tp == 4) hipLaunchKernelGGL((lgd_tp_kernel<5, 4>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns, magic_nch);
+  else if (u == 7 && tp == 4) hipLaunchKernelGGL((lgd_tp_kernel<7, 4>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns, magic_nch);
+  else if (u == 5 && tp == 2) hipLaunchKernelGGL((lgd_tp_kernel<5, 2>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns, magic_nch);
+  else if (u == 7 && tp == 2) hipLaunchKernelGGL((lgd_tp_kernel<7, 2>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns, magic_nch);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -1042,7 +1002,7 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, c
   if (generic) {
     if (chunk != LGD_GENERIC_CHUNK) return hipErrorInvalidValue;
     if (tp == 4) return launch_scan_generic<4>(nch, segs, n_seg, F, s);
-    if (tp == 2) return launch_scan_generic<2>(nch, segs, n_seg, F, s);
+    if (tp == 2) return launch_scan_generic<4>(nch, segs, n_seg, F, s);
     return launch_scan_generic<0>(nch, segs, n_seg, F, s);
   }
   if (nch > 8 || nch == 7) return hipErrorInvalidValue;
