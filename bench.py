@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msamples/s scanned (48 kHz stereo f32), BASELINE.json.
 
-  python bench.py [--gpus N --steps K --warmup W]            # N = 1
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|c4|c5]
 
-Workload (BASELINE.json configs[1]): per GPU one synthetic
-60 min 48 kHz stereo f32 buffer (172 800 000 frames, 1 382 400 000 B) resident
-in HBM; one "step" = one full EBU R128 scan of it: K-weighting + 100 ms block
-energies + sample peak kernel, gating / LRA epilogue (true peak off = C2; pass
---workload c3 for the reference's always-on true peak).  With N > 1 every rank
-scans its own buffer as one track of an N-track album and each step ends with
-the album reduction over RCCL (weak scaling).  `value` = samples of all ranks /
-max-over-ranks wall time of K steps.
+N > 1 may be started either way: `python bench.py --gpus N` spawns its N ranks itself (fresh
+child processes, before this process touches a GPU), and under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  One rank per GPU, RCCL.
+
+Workloads (BASELINE.json configs; all synthetic, generated in HBM, every
+value on the S16 grid; a "step" = one full scan of the rank's tracks incl. gating / LRA epilogue
+and, in album mode, the album reduction):
+  c2  configs[1]  one 60 min 48 kHz stereo f32 buffer per GPU (1 382 400 000 B), true peak OFF
+                  (a build-only switch).  The contract `value` at N = 1; the same line carries a
+                  "c3" object, because the reference always has true peak on (scan.c:203-207).
+                  N > 1: every rank scans its own buffer as one track of an N-track album (weak).
+  c3  configs[2]  the same buffer with the 4x true-peak interpolator = the reference's semantics.
+  c4  configs[3]  album of 1000 stereo 48 kHz tracks, track t = 180 s + (t mod 7) * 30 s, seed t,
+                  dealt round-robin (t mod N), true peak on, album result over all 1000 (strong).
+                  The default workload for N > 1.
+  c5  configs[4]  album of 64 tracks cycling 44.1 / 48 / 96 / 192 kHz x mono / stereo / 5.1, 120 s
+                  each, round-robin over the ranks, true peak on (4x / 2x / none by rate).
+`value` = samples of all ranks per step / max-over-ranks wall time per step.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -23,222 +36,504 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+METRIC = "Msamples/s scanned (48 kHz stereo f32)"
 
 
-def cpu_baseline(pcm_host, rate, seconds):
-    """CPU restatement of the reference path (oracle/, scan.c + libebur128 1.2.4
-    semantics, all five modes on as scan.c:203-207), 1 thread, bounded sample."""
-    from oracle import lgoracle
-    import numpy as np
-    lgoracle.lib()
-    st = lgoracle.State(pcm_host.shape[1], rate)
-    t0 = time.perf_counter()
-    st.add(pcm_host, chunk=4096)
-    loud = st.loudness()
-    st.lra()
-    st.peak()
-    dt = time.perf_counter() - t0
-    return dict(value=round(pcm_host.size / dt / 1e6, 2), unit="Msamples/s", cores=1, kind="port",
-                sample="first %d s of the same buffer, 1 thread, oracle -O2, all modes incl. 4x true peak "
-                       "(CPU restatement of reference path); %.2f s wall; %.3f LUFS" % (seconds, dt, loud))
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # (a step is ~0.3 ms: a few thousand of them so that pipeline fill / drain and the clock
-    # ramp of the first milliseconds do not weigh on the figure; 100 steps read 5 % low)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
-    ap.add_argument("--minutes", type=float, default=60.0)
+    ap.add_argument("--steps", type=int, default=0, help="0 = the workload's default")
+    ap.add_argument("--warmup", type=int, default=-1, help="-1 = the workload's default")
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "c4", "c5"],
+                    help="auto: c2 (with the c3 object) on one GPU, c4 on several")
+    ap.add_argument("--minutes", type=float, default=60.0, help="c2 / c3: buffer length")
+    ap.add_argument("--tracks", type=int, default=0, help="c4 / c5: number of tracks (0 = 1000 / 64)")
+    ap.add_argument("--track-scale", type=float, default=1.0, help="c4 / c5: scales every track length (tests)")
     ap.add_argument("--material", default="steps", choices=["steps", "adversarial", "silence", "noise"],
-                    help="steps: SURVEY 8d programme material; adversarial: constant-amplitude fs/4 sine "
-                         "sampled on its peaks (no true-peak window can be pruned)")
-    ap.add_argument("--no-tp-prune", action="store_true")
-    ap.add_argument("--debug-counters", action="store_true",
-                    help="measurement build only (LOUDSCAN_LIB=.../libloudscan_hip_dbg.so): true-peak pruning statistics of one scan")
+                    help="c2 / c3: steps = SURVEY 8d programme material; adversarial = constant-amplitude fs/4 "
+                         "sine sampled on its peaks (no true-peak output can be pruned)")
+    ap.add_argument("--no-c3", action="store_true", help="c2 on one GPU: skip the c3 object")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer (PCIe-inclusive) figures")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=int, default=1800, help="audio seconds of the 1-thread CPU leg")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the CPU leg (0 = host cores, <= 16)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--seg-subblocks", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--warm-subblocks", type=int, default=-1)
-    ap.add_argument("--cpu-seconds", type=int, default=1800)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tp-prune", action="store_true")
     ap.add_argument("--debug", type=int, default=0, help="kernel floor measurement: 1 no loads, 2 no arithmetic")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal of the N>1 path on one GPU: RCCL group of one rank, album exchange every step")
     ap.add_argument("--serial", action="store_true",
                     help="no stream pipelining of consecutive scans (the mode rocprofv3 kernel durations are quoted in)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the launcher")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no GPU work: ranks rendezvous, all-reduce one number, rank 0 prints a JSON line")
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
+
+# --------------------------------------------------------------------------- launcher --
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_children(n, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh processes, one per GPU.  Nothing in
+    this (parent) process has touched a GPU; it only relays rank 0's line and the exit codes."""
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), LGD_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    for ln in out.splitlines():   # stdout carries rank 0's JSON line only (libraries chat on stdout too)
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+# ----------------------------------------------------------------------- CPU baseline --
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_worker(args):
+    """One worker of the multi-process leg: its own track, as rgbpm2 hands out albums
+    (/root/reference/bin/rgbpm2:170-175).  Returns (samples, seconds of the scan alone)."""
+    idx, seconds, rate, start_at = args
     from loudgain_amd import synth
-    from loudgain_amd.device import DeviceScanner
-    from loudgain_amd.album import DistributedAlbumScanner
+    from oracle import lgoracle
+    lgoracle.lib()
+    pcm = synth.track_numpy(seconds * rate, 2, rate, seed=1000 + idx)
+    while time.time() < start_at:   # all workers scan at the same time
+        time.sleep(0.001)
+    t0 = time.perf_counter()
+    st = lgoracle.State(2, rate).add(pcm, chunk=4096)
+    st.loudness(), st.lra(), st.peak()
+    return pcm.size, time.perf_counter() - t0, t0
 
-    rank = int(os.environ.get("RANK", "0"))
+
+def cpu_baseline(args, rate=48000):
+    """CPU restatement of the reference path (oracle/: scan.c + libebur128 1.2.4 semantics, all five
+    modes on as scan.c:203-207, i.e. INCLUDING the 4x true peak -- the GPU figure it stands next to
+    is c3).  Leg (i): 1 process, 1 thread -- how loudgain runs.  Leg (ii): P processes, one track
+    each -- how bin/rgbpm2 parallelises.  Runs before this process touches the GPU."""
+    import multiprocessing as mp
+    from loudgain_amd import synth
+    from oracle import lgoracle
+    lgoracle.lib()
+    secs = int(min(args.cpu_seconds, args.minutes * 60))
+    pcm = synth.track_numpy(secs * rate, 2, rate, seed=0)
+    t0 = time.perf_counter()
+    st = lgoracle.State(2, rate).add(pcm, chunk=4096)
+    loud = st.loudness()
+    st.lra(), st.peak()
+    dt = time.perf_counter() - t0
+    one = pcm.size / dt / 1e6
+    del pcm
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    nproc = args.cpu_procs or min(cores, 16)   # (a GPU box gives one GPU's job a 16-core share)
+    wsecs = max(10, min(secs, 600))
+    multi = None
+    if nproc > 1:
+        ctx = mp.get_context("fork")           # (no GPU state exists in this process yet)
+        with ctx.Pool(nproc) as pool:
+            start_at = time.time() + 1.5 + 0.012 * wsecs
+            res = pool.map(_cpu_worker, [(i, wsecs, rate, start_at) for i in range(nproc)])
+        wall = max(t0 + d for _, d, t0 in res) - min(t0 for _, _, t0 in res)
+        multi = dict(value=round(sum(n for n, _, _ in res) / wall / 1e6, 2), unit="Msamples/s", cores=nproc,
+                     model=_cpu_model(), host_cores=cores,
+                     sample="%d processes, one %d s 48 kHz stereo track each (as bin/rgbpm2 hands out work), "
+                            "%.2f s wall" % (nproc, wsecs, wall))
+    return dict(value=round(one, 2), unit="Msamples/s", cores=1, kind="port", model=_cpu_model(),
+                stands_next_to="c3 (the reference always computes the 4x true peak, scan.c:203-207)",
+                sample="first %d s of a c2/c3-style track (numpy Philox twin of the GPU generator), 1 thread, oracle "
+                       "-O2, all modes incl. 4x true peak (CPU restatement of reference path); %.2f s wall; %.3f LUFS"
+                       % (secs, dt, loud),
+                multi_process=multi)
+
+
+# -------------------------------------------------------------------------- workloads --
+def c4_track_frames(t, rate=48000, scale=1.0):
+    return int((180 + (t % 7) * 30) * rate * scale)
+
+
+C5_RATES = (44100, 48000, 96000, 192000)
+C5_CHANNELS = (1, 2, 6)
+
+
+def c5_track_spec(t, scale=1.0):
+    rate = C5_RATES[t % 4]
+    ch = C5_CHANNELS[(t // 4) % 3]
+    return rate, ch, int(120 * rate * scale)
+
+
+def build_tracks(args, workload, rank, world, dev):
+    """-> (list of device tensors, list of rates, description, true_peak, album)"""
+    import torch
+    from loudgain_amd import synth
+    if workload in ("c2", "c3"):
+        rate, ch = 48000, 2
+        frames = int(round(args.minutes * 60 * rate))
+        if args.material == "adversarial":
+            pcm = synth.adversarial_torch(frames, ch, device=dev)
+        elif args.material == "silence":
+            pcm = torch.zeros((frames, ch), dtype=torch.float32, device=dev)
+        elif args.material == "noise":
+            pcm = synth.track_torch(frames, ch, rate, seed=rank, step_s=1e9, device=dev, sine=False)
+        else:
+            pcm = synth.track_torch(frames, ch, rate, seed=rank, device=dev)
+        return [pcm], [rate]
+    if workload == "c4":
+        n = args.tracks or 1000
+        mine = range(rank, n, world)
+        return ([synth.track_torch(c4_track_frames(t, scale=args.track_scale), 2, 48000, seed=t, device=dev)
+                 for t in mine], [48000] * len(mine))
+    n = args.tracks or 64
+    tracks, rates = [], []
+    for t in range(rank, n, world):
+        rate, ch, frames = c5_track_spec(t, args.track_scale)
+        tracks.append(synth.track_torch(frames, ch, rate, seed=t, device=dev))
+        rates.append(rate)
+    return tracks, rates
+
+
+def describe(args, workload, world, distributed):
+    if workload in ("c2", "c3"):
+        tp = " + 4x true peak" if workload == "c3" else ", no true peak"
+        mat = "" if args.material == "steps" else " [%s material]" % args.material
+        alb = "; %d-track album, RCCL album reduce per step" % world if distributed else ""
+        return "%s: %g min 48 kHz stereo f32 per GPU, K-filter + gated loudness + LRA%s%s%s" % (
+            workload.upper(), args.minutes, tp, mat, alb)
+    if workload == "c4":
+        return ("C4: album of %d stereo 48 kHz tracks of 180 + (t mod 7) * 30 s%s, round-robin over %d GPU(s), "
+                "K-filter + gated loudness + LRA + 4x true peak per track, album loudness / range / peak over all"
+                % (args.tracks or 1000, "" if args.track_scale == 1.0 else " (x %g)" % args.track_scale, world))
+    return ("C5: album of %d tracks cycling 44.1/48/96/192 kHz x mono/stereo/5.1, 120 s each%s, round-robin over "
+            "%d GPU(s), per-channel K-weighting (libebur128 default map), 4x / 2x / no interpolator by rate"
+            % (args.tracks or 64, "" if args.track_scale == 1.0 else " (x %g)" % args.track_scale, world))
+
+
+# ------------------------------------------------------------------------- measurement --
+class Runner:
+    def __init__(self, args, rank, world, local_rank):
+        import torch
+        from loudgain_amd.device import DeviceScanner
+        self.torch = torch
+        self.args, self.rank, self.world = args, rank, world
+        self.dev = torch.device("cuda", local_rank)
+        self.sc = DeviceScanner(local_rank)
+        a, sc = args, self.sc
+        if a.chunk:
+            sc.set_param("chunk", a.chunk)
+        if a.seg_subblocks:
+            sc.set_param("seg_subblocks", a.seg_subblocks)
+        if a.waves_per_cu:
+            sc.set_param("waves_per_cu", a.waves_per_cu)
+        if a.warm_subblocks >= 0:
+            sc.set_param("warm_subblocks", a.warm_subblocks)
+        if a.debug:
+            sc.set_param("debug", a.debug)
+        if a.no_tp_prune:
+            sc.set_param("tp_prune", 0)
+        self.stream = torch.cuda.Stream(device=self.dev)
+
+    def kernel_stats(self, tracks, rates, true_peak, album, launches=64, settle=300):
+        """The kernels that read PCM (scan kernels + the true-peak kernels behind them), timed with
+        hipEvents on the launch stream around every launch, launches strictly serial -- the mode the
+        committed rocprofv3 kernel traces (`bench.py --serial`) are taken in.  In the timed region of
+        `run` consecutive scans pipeline on two streams, where a per-launch bracket would include
+        queueing behind the previous scan."""
+        sc = self.sc
+        sc.set_param("overlap", 0)
+        sc.plan(tracks, rates, true_peak=true_peak, album=album)
+        for _ in range(settle):           # clocks and caches in the steady state of that mode
+            sc.execute(self.stream)
+        sc.fetch()
+        for _ in range(launches):
+            sc.execute(self.stream)
+        sc.fetch()
+        return sc.kernel_ms_stats(launches)
+
+    def run(self, job, steps, warmup, distributed):
+        torch = self.torch
+        import torch.distributed as dist
+
+        def barrier():
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            job.execute(self.stream)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.execute(self.stream)
+        results = job.fetch()  # synchronises the streams, copies the numbers out
+        barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, results
+
+    def step_times(self, job, n):
+        """median / min over n individually timed (synchronised) steps"""
+        ts = []
+        for _ in range(n):
+            self.torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            job.execute(self.stream)
+            job.fetch()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return dict(median=round(statistics.median(ts), 4), min=round(min(ts), 4), n=n,
+                    note="one scan at a time incl. fetch (host launch + D2H of the results included)")
+
+
+def roofline_block(algo_bytes, ks, dt_step, traffic, timing, kernels):
+    achieved = algo_bytes / (ks["scan_mean_ms"] * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "kernel": kernels, "kernel_ms_mean": round(ks["scan_mean_ms"], 4),
+        "kernel_ms_min": round(ks["scan_min_ms"], 4),
+        "scan_kernel_only_ms_mean": round(ks["scan_only_mean_ms"], 4), "launches_timed": ks["n"],
+        "algorithmic_bytes_per_launch": algo_bytes,
+        # the same bytes over the wall time of one step of the timed region (scans pipelined,
+        # epilogue and launch overheads included)
+        "sustained_GBs": round(algo_bytes / dt_step / 1e9, 1),
+        "sustained_frac": round(algo_bytes / dt_step / 1e9 / HBM_PEAK_GBS, 4),
+        "timing": timing,
+    }
+
+
+def traffic_from_profiles(tag):
+    p = os.path.join(ROOT, "profiles", "traffic_%s.json" % tag)
+    try:
+        return json.load(open(p)).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def h2d_inclusive(run, pcm, rate, true_peak):
+    """Host-buffer entry (what scan_pcm_* / scan_file pay): pinned host -> HBM copy + scan + fetch.
+    f32 upload, and S16 upload + on-device widening (the grid scan.c:414 puts every input on)."""
+    torch = run.torch
+    sc = run.sc
+    out = {}
+    n = pcm.numel()
+    host32 = torch.empty(pcm.shape, dtype=torch.float32).pin_memory()
+    host32.copy_(pcm)
+    host16 = torch.empty(pcm.shape, dtype=torch.int16).pin_memory()
+    host16.copy_((pcm * 32768.0).to(torch.int16))
+    dev32 = torch.empty_like(pcm)
+    dev16 = torch.empty(pcm.shape, dtype=torch.int16, device=pcm.device)
+    sc.set_param("overlap", 0)
+    sc.plan([dev32], rate, true_peak=true_peak, album=False)
+    for name in ("f32", "s16"):
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(run.stream):
+                if name == "f32":
+                    dev32.copy_(host32, non_blocking=True)
+                else:
+                    dev16.copy_(host16, non_blocking=True)
+                    sc._chk(sc.L.lgd_convert_s16(dev16.data_ptr(), dev32.data_ptr(), n, run.stream.cuda_stream))
+            sc.execute(run.stream)
+            sc.fetch()
+            ts.append(time.perf_counter() - t0)
+        t = min(ts[1:])
+        out[name] = dict(msamples_per_s=round(n / t / 1e6, 1), ms=round(t * 1e3, 3),
+                         pcie_GBs=round(n * (4 if name == "f32" else 2) / t / 1e9, 1))
+    out["note"] = ("pinned host buffer -> HBM -> scan -> results, one buffer at a time, no overlap of copy and "
+                   "scan; PCIe-bound; never the bench `value`")
+    return out
+
+
+def main():
+    args = parse_args()
+    argv = sys.argv[1:]
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1 and not os.environ.get("LGD_BENCH_CHILD"):
+        sys.exit(launch_children(args.gpus, argv))   # before anything here touches a GPU
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+
+    if args.launcher_selftest:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": True, "world_size": dist.get_world_size(),
+                              "backend": dist.get_backend(), "sum": float(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+
+    # Exactly ONE line may reach stdout (rank 0's JSON): libraries write banners there too (RCCL prints
+    # its version when the first communicator is made), so fd 1 is pointed at stderr from here on and
+    # the line goes out through a duplicate of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    workload = args.workload
+    if workload == "auto":
+        workload = "c2" if world == 1 else "c4"
+
+    # the CPU legs first: they fork worker processes, which must not happen after GPU initialisation
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    import torch
+    import torch.distributed as dist
+    from loudgain_amd.album import DistributedAlbumScanner
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_dist
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
-    rate, ch = 48000, 2
-    frames = int(round(args.minutes * 60 * rate))
-    true_peak = args.workload == "c3"
-    if args.material == "adversarial":
-        pcm = synth.adversarial_torch(frames, ch, device=dev)
-    elif args.material == "silence":
-        pcm = torch.zeros((frames, ch), dtype=torch.float32, device=dev)
-    elif args.material == "noise":   # stationary noise, no level steps, no sine
-        pcm = synth.track_torch(frames, ch, rate, seed=rank, step_s=1e9, device=dev, sine=False)
-    else:
-        pcm = synth.track_torch(frames, ch, rate, seed=rank, device=dev)
+    run = Runner(args, rank, world, local_rank)
+    sc = run.sc
+    tracks, rates = build_tracks(args, workload, rank, world, dev)
     torch.cuda.synchronize()
-
-    sc = DeviceScanner(local_rank)
-    if args.chunk:
-        sc.set_param("chunk", args.chunk)
-    if args.seg_subblocks:
-        sc.set_param("seg_subblocks", args.seg_subblocks)
-    if args.waves_per_cu:
-        sc.set_param("waves_per_cu", args.waves_per_cu)
-    if args.warm_subblocks >= 0:
-        sc.set_param("warm_subblocks", args.warm_subblocks)
-    if args.debug:
-        sc.set_param("debug", args.debug)
-    if args.serial:
-        sc.set_param("overlap", 0)
-    if args.no_tp_prune:
-        sc.set_param("tp_prune", 0)
-    stream = torch.cuda.Stream(device=dev)
-
-    # Kernel timing for the roofline.  In the timed region below consecutive scans
-    # pipeline on two streams (the next scan's workgroups fill the GPU while the
-    # previous one drains), so a per-launch hipEvent bracket there includes queueing
-    # behind the previous launch.  The dominant kernel is therefore timed first, same
-    # process and buffers, with the launches strictly serial on the launch stream
-    # (hipEvents recorded on that stream around every launch) -- the mode the committed
-    # rocprofv3 kernel trace (`bench.py --serial`) is taken in.
-    overlapped = not args.serial
-    ks = None
-    if overlapped:
-        sc.set_param("overlap", 0)
-        sc.plan([pcm], rate, true_peak=true_peak, album=False)
-        for _ in range(300):  # ~0.1 s: clocks and caches in the steady state of that mode
-            sc.execute(stream)
-        sc.fetch()
-        for _ in range(64):
-            sc.execute(stream)
-        sc.fetch()
-        ks = sc.kernel_ms_stats(64)
-        sc.set_param("overlap", 1)
-
+    true_peak = workload != "c2"
+    album = workload in ("c4", "c5")
+    my_samples = sum(int(t.numel()) for t in tracks)
+    algo_bytes = my_samples * 4           # SURVEY.md 8d: 4 B read per sample, writes ~ 0
     if distributed:
-        job = DistributedAlbumScanner(sc, [pcm], rate, true_peak=true_peak, always_exchange=True)
+        t = torch.tensor([my_samples], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        total_samples = int(t.item())
     else:
-        job = sc.plan([pcm], rate, true_peak=true_peak, album=False)
+        total_samples = my_samples
+    steps = args.steps or {"c2": 2000, "c3": 2000, "c4": max(10, 20 * world), "c5": 200}[workload]
+    warmup = args.warmup if args.warmup >= 0 else {"c2": 20, "c3": 20, "c4": 3, "c5": 5}[workload]
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        job.execute(stream)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.execute(stream)
-    results = job.fetch()  # synchronises the stream, copies the numbers out
-    barrier()
-    dt = time.perf_counter() - t0
+    overlapped = not args.serial
+    settle = {"c2": 300, "c3": 300, "c4": 3, "c5": 20}[workload]
+    launches = {"c2": 64, "c3": 64, "c4": 8, "c5": 32}[workload]
+    ks = run.kernel_stats(tracks, rates, true_peak, album and not distributed, launches, settle)
+    sc.set_param("overlap", 1 if overlapped else 0)
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    samples_per_step = frames * ch * world
-    value = samples_per_step * args.steps / dt / 1e6
-    if ks is None:
-        ks = sc.kernel_ms_stats(min(args.steps, 64))
+        job = DistributedAlbumScanner(sc, tracks, rates, true_peak=true_peak, always_exchange=True)
+        if not overlapped:
+            sc.set_param("overlap", 0)
+    else:
+        job = sc.plan(tracks, rates, true_peak=true_peak, album=album)
+    dt, results = run.run(job, steps, warmup, distributed)
+    value = total_samples * steps / dt / 1e6
     info = sc.plan_info()
-    algo_bytes = frames * ch * 4  # SURVEY.md 8d: 4 B read per sample, writes ~ 0
-    achieved = algo_bytes / (ks["scan_mean_ms"] * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
 
-    if args.debug_counters and rank == 0:
-        import ctypes as C
-        buf = (C.c_ulonglong * 8)()
-        sc.L.lgd_debug_counters(buf, 1)
-        sc.plan([pcm], rate, true_peak=true_peak, album=False)
-        sc.execute(stream)
-        sc.fetch()
-        sc.L.lgd_debug_counters(buf, 1)
-        names = ["windows", "candidates", "queue_passes", "own_bit_iters", "queue_overflow_tiles",
-                 "tiles_with_candidates", "tiles", "publishes"]
-        print(json.dumps({"tp_debug_counters_one_scan": dict(zip(names, list(buf)[:8]))}), file=sys.stderr, flush=True)
+    collective = None
+    if distributed:
+        r1n = job.shard.rec1.numel()
+        collective = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)",
+                      "world_size": dist.get_world_size(),
+                      "per_step": "all_gather of album record 1 (%d doubles per rank) + all_gather of record 2 "
+                                  "(2 doubles per rank), on a side stream behind the scan" % r1n,
+                      "bytes_gathered_per_rank_per_step": 8 * (r1n + 2) * dist.get_world_size()}
+
+    line = None
     if rank == 0:
         tr = results[0][0]
+        kernels = ("lgd_scan_kernel" if not true_peak else
+                   "lgd_scan_kernel + lgd_peak_reduce_kernel + lgd_tp_kernel (everything that reads PCM)")
+        timing = ("%d serial launches before the timed region (the region itself pipelines consecutive scans on "
+                  "two streams: see sustained_frac)" % launches if overlapped else "serial launches, as the timed region")
         line = {
-            "metric": "Msamples/s scanned (48 kHz stereo f32)",
-            "value": round(value, 1),
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
+            "metric": METRIC, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong" if workload in ("c4", "c5") else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "%s: %g min 48 kHz stereo f32 per GPU, K-filter + gated loudness + LRA%s%s"
-                            % (args.workload.upper(), args.minutes,
-                               " + 4x true peak" if true_peak else ", no true peak",
-                               "; %d-track album, RCCL album reduce per step" % world if distributed else ""),
-                "frames_per_gpu": frames, "channels": ch, "rate": rate,
+                "workload": describe(args, workload, world, distributed),
+                "tracks_this_rank": len(tracks), "samples_per_step_all_ranks": total_samples,
                 "chunk": info["chunk"], "segments": info["segments"],
-                "x_realtime": round(value * 1e6 / (rate * ch), 0),
-                "mframes_per_s": round(value / ch, 1),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "lgd_scan_kernel", "kernel_ms_mean": round(ks["scan_mean_ms"], 4),
-                "kernel_ms_min": round(ks["scan_min_ms"], 4), "launches_timed": ks["n"],
-                "algorithmic_bytes_per_launch": algo_bytes,
-                # the same bytes over the wall time of one step of the timed region (scans
-                # pipelined, epilogue and launch overheads included)
-                "sustained_GBs": round(algo_bytes * world / (dt / args.steps) / 1e9 / world, 1),
-                "sustained_frac": round(algo_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                "timing": ("64 serial launches before the timed region (the region itself pipelines "
-                           "consecutive scans on two streams: see sustained_frac)" if overlapped else "launches of the timed region"),
-            },
+            "roofline": roofline_block(algo_bytes, ks, dt / steps, traffic_from_profiles(workload), timing, kernels),
             "result": {"loudness": tr["loudness"], "lra": tr["lra"], "peak": tr["peak"],
                        "n_abs": tr["n_abs"], "n_rel": tr["n_rel"], "n_st": tr["n_st"]},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            secs = int(min(args.cpu_seconds, args.minutes * 60))
-            host = pcm[: secs * rate].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(host, rate, secs)
-        print(json.dumps(line), flush=True)
+        if workload in ("c2", "c3"):
+            frames = tracks[0].shape[0]
+            line["config"].update(frames_per_gpu=frames, channels=2, rate=48000,
+                                  x_realtime=round(value * 1e6 / (48000 * 2), 0),
+                                  mframes_per_s=round(value / 2, 1))
+        if results[1] is not None:
+            al = results[1] if isinstance(results[1], dict) else results[1][0]
+            line["result"]["album"] = {"loudness": al["loudness"], "lra": al["lra"], "peak": al["peak"],
+                                       "n_abs": al["n_abs"], "n_rel": al["n_rel"], "n_st": al["n_st"]}
+        if collective:
+            line["collective"] = collective
+
+    # one GPU, c2: the reference's own semantics (true peak on) beside it, standard and adversarial material
+    if rank == 0 and world == 1 and workload == "c2" and not args.no_c3 and not distributed:
+        from loudgain_amd import synth
+        c3steps = max(10, steps // 2)
+        ks3 = run.kernel_stats(tracks, rates, True, False, 64, 300)
+        sc.set_param("overlap", 1 if overlapped else 0)
+        job3 = sc.plan(tracks, rates, true_peak=True, album=False)
+        dt3, res3 = run.run(job3, c3steps, warmup, False)
+        c3 = {"workload": describe(args, "c3", 1, False),
+              "value": round(my_samples * c3steps / dt3 / 1e6, 1), "unit": "Msamples/s",
+              "steps": c3steps, "ms_per_step": round(dt3 / c3steps * 1e3, 4),
+              "roofline": roofline_block(algo_bytes, ks3, dt3 / c3steps, traffic_from_profiles("c3"),
+                                         "64 serial launches; pipelined timed region",
+                                         "lgd_scan_kernel + lgd_peak_reduce_kernel + lgd_tp_kernel"),
+              "peak": res3[0][0]["peak"], "true_peak_pruning": "exact; data dependent -- see adversarial"}
+        if args.material == "steps" and args.minutes >= 1:
+            adv = synth.adversarial_torch(tracks[0].shape[0], 2, device=dev)
+            ksa = run.kernel_stats([adv], rates, True, False, 32, 100)
+            aach = algo_bytes / (ksa["scan_mean_ms"] * 1e-3) / 1e9
+            c3["adversarial"] = {
+                "material": "constant-amplitude fs/4 sine sampled on its peaks: sample peak == true peak in every "
+                            "window, no interpolator output can be pruned",
+                "kernel_ms_mean": round(ksa["scan_mean_ms"], 4), "achieved": round(aach, 1),
+                "frac": round(aach / HBM_PEAK_GBS, 4)}
+            del adv
+        line["c3"] = c3
+        line["step_ms"] = run.step_times(sc.plan(tracks, rates, true_peak=False, album=False), 20)
+        if not args.no_h2d:
+            line["h2d_inclusive"] = h2d_inclusive(run, tracks[0], rates[0], True)
+    if rank == 0:
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     if distributed:
         dist.destroy_process_group()
 

@@ -135,23 +135,6 @@ __device__ __forceinline__ int wave_incl_sum_i32(int v) {
   return v;
 }
 
-#ifdef LGD_DEBUG_MODES
-// measurement builds: [0] interpolator windows seen, [1] candidates, [2] queue passes,
-// [3] own-bits iterations, [4] tiles that overflowed the queue, [5] tiles with candidates, [6] tiles
-__device__ unsigned long long lgd_dbg_counters[8];
-extern "C" hipError_t lgd_debug_counters(unsigned long long *out, int reset) {
-  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(lgd_dbg_counters), 8 * sizeof(unsigned long long));
-  if (e == hipSuccess && reset) {
-    unsigned long long z[8] = {0};
-    e = hipMemcpyToSymbol(HIP_SYMBOL(lgd_dbg_counters), z, sizeof(z));
-  }
-  return e;
-}
-#define LGD_DBG_COUNT(i_, v_) do { if (lane == 0) atomicAdd(&lgd_dbg_counters[i_], (unsigned long long)(v_)); } while (0)
-#else
-#define LGD_DBG_COUNT(i_, v_) do { } while (0)
-#endif
-
 // ------------------------------------------------------------ scan kernel ---
 // One workgroup per segment, one WAVEFRONT PER CHANNEL: the nch waves of a
 // workgroup stage one interleaved tile in LDS together and each filters its own
