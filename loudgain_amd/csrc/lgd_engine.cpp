@@ -500,28 +500,30 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   std::map<Key, size_t> group_of;
   std::vector<std::vector<LgdSeg>> group_segs;
 
-  // segment length: spread all sub-blocks over ~waves_per_cu waves per CU
-  // (one wave per segment and channel: total_e counts sub-blocks x channels)
-  const uint64_t target_waves = (uint64_t)c->n_cu * (uint64_t)c->p_waves_per_cu;
-  uint64_t seg_sb = c->p_seg_sb ? (uint64_t)c->p_seg_sb
-                                : (c->total_e + target_waves - 1) / (target_waves ? target_waves : 1);
+  // Segment length, per (rate, channels) -- every such group is one launch and has to fill the
+  // GPU by itself.  A CU holds `slots` workgroups of the group's kernel (2 waves per SIMD for
+  // mono / stereo: waves_per_cu / channels workgroups; floor(12 / channels) at 3 waves per SIMD
+  // for 3 .. 8 channels, 16 waves per CU for the 9 .. 16-channel kernel).  The group's sub-blocks
+  // are cut into `rounds` x slots segments of at most ~48 sub-blocks: ONE full round for a
+  // C2-sized plan (1000 segments of 36: measured best; 1.5 rounds cost 25 %), many rounds of
+  // short segments for album-sized plans (a 1000-track album as a few hundred long segments
+  // left half the GPU idle in its last round), never below min_seg (the 200 ms warm-up in front
+  // of a segment has to stay small against it).
   const uint64_t min_seg = (uint64_t)std::max<long>(4, 3 * c->p_warm_sb);
-  if (!c->p_seg_sb && seg_sb < min_seg) seg_sb = min_seg;  // keep the warm-up overhead bounded
-  if (seg_sb < 1) seg_sb = 1;
-  // Workgroups of many waves (3+ channels) fill a CU in coarse steps: at 3 waves per SIMD a
-  // CU holds floor(12 / channels) of them (16 waves per CU for the 9..16-channel kernel),
-  // and a launch with a few more workgroups than slots runs two rounds.  Tracks of each
-  // such layout together get one workgroup per slot (measured on 5 channels: 600 -> 512
-  // workgroups, 1.31 -> see DESIGN 6.0).
-  uint64_t multi_sb[LGD_GROUP_CH + 1] = {0};
-  for (uint32_t t = 0; t < n; ++t)
-    if (tracks[t].channels > 2)
-      multi_sb[std::min<unsigned>(tracks[t].channels, LGD_GROUP_CH)] += (uint64_t)c->meta[t].n_sb;
-  uint64_t seg_sb_multi[LGD_GROUP_CH + 1];
-  for (unsigned k = 0; k <= LGD_GROUP_CH; ++k) {
-    const unsigned per_cu = k == 0 ? 1 : (k > 8 ? std::max(1u, 16u / k) : std::max(1u, 12u / k));
+  const uint64_t max_seg = 48;
+  struct RC { unsigned rate, ch; bool operator<(const RC &o) const { return rate != o.rate ? rate < o.rate : ch < o.ch; } };
+  std::map<RC, uint64_t> key_sb, key_seg;
+  for (uint32_t t = 0; t < n; ++t) key_sb[RC{tracks[t].rate, tracks[t].channels}] += (uint64_t)c->meta[t].n_sb;
+  for (const auto &kv : key_sb) {
+    const unsigned k = std::min<unsigned>(kv.first.ch, LGD_GROUP_CH);
+    const unsigned per_cu = k <= 2 ? std::max(1u, (unsigned)c->p_waves_per_cu / k)
+                                   : (k > 8 ? std::max(1u, 16u / k) : std::max(1u, 12u / k));
     const uint64_t slots = (uint64_t)c->n_cu * per_cu;
-    seg_sb_multi[k] = c->p_seg_sb ? seg_sb : std::max<uint64_t>(min_seg, (multi_sb[k] + slots - 1) / slots);
+    const uint64_t rounds = std::max<uint64_t>(1, (kv.second + slots * max_seg - 1) / (slots * max_seg));
+    uint64_t seg = (kv.second + rounds * slots - 1) / (rounds * slots);
+    if (c->p_seg_sb) seg = (uint64_t)c->p_seg_sb;
+    else seg = std::max(seg, min_seg);
+    key_seg[kv.first] = std::max<uint64_t>(1, seg);
   }
 
   for (uint32_t t = 0; t < n; ++t) {
@@ -529,7 +531,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     LgdTrackMeta &m = c->meta[t];
     const int s100 = m.s100;
     const uint64_t nsb = (uint64_t)m.n_sb;
-    const uint64_t seg_t = tr.channels > 2 ? seg_sb_multi[std::min<unsigned>(tr.channels, LGD_GROUP_CH)] : seg_sb;
+    const uint64_t seg_t = key_seg[RC{tr.rate, tr.channels}];
     const uint64_t nseg = nsb ? (nsb + seg_t - 1) / seg_t : 1;
     m.n_seg = (int)nseg;
     m.peak_off = (long long)c->total_peak_floats;
