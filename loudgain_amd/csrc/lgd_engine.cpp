@@ -34,8 +34,11 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
                                                 const float *peaks, double *p1, double *p2,
                                                 double *pmax_s, double *res, double abs_gate,
                                                 double rel_factor, int do_tp, hipStream_t s);
+extern "C" size_t lgd_lra_pick_bytes(void);
 extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
-                                     double minus20, hipStream_t s);
+                                     double minus20, const int *big_idx, int n_big, unsigned *hist,
+                                     double *part, void *picks, double *cand, const long long *cand_off,
+                                     hipStream_t s);
 extern "C" hipError_t lgd_launch_album_part1(const double *res, const LgdAlbumMeta *albums,
                                              int n_albums, double *heads, hipStream_t s);
 extern "C" hipError_t lgd_launch_album_stage2(const LgdSlice *slices, int n_slices,
@@ -229,7 +232,7 @@ static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at m
 struct lgd_ctx {
   int device = 0;
   long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 0,
-       p_album_slots = 0, p_tp_prune = 1;
+       p_album_slots = 0, p_tp_prune = 1, p_album_world = 8;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -259,6 +262,17 @@ struct lgd_ctx {
     float *d_hint = nullptr;        // per track and channel: sample peak of the whole track (LgdSeg::hint)
     unsigned char *d_tp_rows = nullptr;  // chunk maxima, 1 KB per (group of 8 tiles, channel) (LgdSeg::tp_rows)
     LgdSeg *d_segs = nullptr;       // descriptors carry pointers into this set's E / peaks
+    // long loudness-range lists (> LGD_LRA_BIG entries): which ranges, and the scratch of the
+    // multi-workgroup kernels (shared by the track launch and the album launch of an execute)
+    int *d_big_tr = nullptr, *d_big_al = nullptr, *d_big_one = nullptr;
+    long long *d_off_tr = nullptr, *d_off_al = nullptr, *d_off_one = nullptr;
+    int n_big_tr = 0, n_big_al = 0;
+    unsigned *d_lra_hist = nullptr;
+    double *d_lra_part = nullptr, *d_lra_cand = nullptr;
+    unsigned char *d_lra_picks = nullptr;
+    size_t cap_big_tr = 0, cap_big_al = 0, cap_big_one = 0, cap_off_tr = 0, cap_off_al = 0, cap_off_one = 0,
+           cap_lra_hist = 0, cap_lra_part = 0, cap_lra_cand = 0, cap_lra_picks = 0;
+    uint64_t lra_dist_cap = 0;  // longest gathered album list the scratch holds (multi-GPU form)
     LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
     LgdRange *h_album_range = nullptr;  // pinned
     size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_segs = 0,
@@ -346,7 +360,8 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
   for (auto &w : c->ws) {
     void *ptrs[] = {w.d_E, w.d_Z, w.d_rec1, w.d_res, w.d_album, w.d_part1, w.d_rec2, w.d_peaks,
                     w.d_segs, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a, w.d_heads,
-                    w.d_album_ranges, w.d_pmax, w.d_hint, w.d_tp_rows};
+                    w.d_album_ranges, w.d_pmax, w.d_hint, w.d_tp_rows, w.d_big_tr, w.d_big_al, w.d_big_one,
+                    w.d_off_tr, w.d_off_al, w.d_off_one, w.d_lra_hist, w.d_lra_part, w.d_lra_cand, w.d_lra_picks};
     for (void *p : ptrs)
       if (p) (void)hipFree(p);
     if (w.h_album_range) (void)hipHostFree(w.h_album_range);
@@ -377,6 +392,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "overlap")) c->p_overlap = value;  // 0: every scan on the caller's stream
   else if (!strcmp(name, "album_slots")) c->p_album_slots = value;  // short-term slots of album record 1
   else if (!strcmp(name, "tp_prune")) c->p_tp_prune = value;  // 0: evaluate every interpolator window
+  else if (!strcmp(name, "album_world")) c->p_album_world = value ? value : 8;  // ranks the multi-GPU album scratch is sized for
   else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
   c->planned = false;
   return LGD_OK;
@@ -683,6 +699,43 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     }
     if (n)
       HIPCHK(hipMemcpy(w.d_ranges, c->ranges.data(), n * sizeof(LgdRange), hipMemcpyHostToDevice));
+    {  // long lists -> multi-workgroup loudness-range kernels
+      std::vector<int> big_tr, big_al, one{0};
+      std::vector<long long> off_tr, off_al, off_one{0};
+      long long need_tr = 0, need_al = 0;
+      for (uint32_t t = 0; t < n; ++t)
+        if (c->ranges[t].n > LGD_LRA_BIG) { big_tr.push_back((int)t); off_tr.push_back(need_tr); need_tr += 2 * c->ranges[t].n; }
+      for (uint32_t a = 0; a < n_albums; ++a)
+        if (aranges[a].n > LGD_LRA_BIG) { big_al.push_back((int)a); off_al.push_back(need_al); need_al += 2 * aranges[a].n; }
+      // multi-GPU form: one gathered list of world x rec1_len entries; room for "album_world" ranks
+      const long long need_dist = (flags & LGD_FLAG_ALBUM_PART1) ? 2ll * c->p_album_world * (long long)c->rec1_len : 0;
+      w.lra_dist_cap = (flags & LGD_FLAG_ALBUM_PART1) ? (uint64_t)c->p_album_world * c->rec1_len : 0;
+      w.n_big_tr = (int)big_tr.size();
+      w.n_big_al = (int)big_al.size();
+      const size_t nb = std::max<size_t>(std::max(big_tr.size(), big_al.size()), need_dist ? 1 : 0);
+      if ((rc = ensure(&w.d_big_tr, &w.cap_big_tr, big_tr.size()))) return rc;
+      if ((rc = ensure(&w.d_big_al, &w.cap_big_al, big_al.size()))) return rc;
+      if ((rc = ensure(&w.d_big_one, &w.cap_big_one, 1))) return rc;
+      if ((rc = ensure(&w.d_off_tr, &w.cap_off_tr, off_tr.size()))) return rc;
+      if ((rc = ensure(&w.d_off_al, &w.cap_off_al, off_al.size()))) return rc;
+      if ((rc = ensure(&w.d_off_one, &w.cap_off_one, 1))) return rc;
+      if (nb) {
+        if ((rc = ensure(&w.d_lra_hist, &w.cap_lra_hist, nb * 65536 * 8))) return rc;  // LGD_LRB_REP copies
+        if ((rc = ensure(&w.d_lra_part, &w.cap_lra_part, nb * 64 * 4 + nb * 64))) return rc;  // partials + block sums
+        if ((rc = ensure(&w.d_lra_picks, &w.cap_lra_picks, nb * lgd_lra_pick_bytes()))) return rc;
+        if ((rc = ensure(&w.d_lra_cand, &w.cap_lra_cand, (size_t)std::max(std::max(need_tr, need_al), need_dist)))) return rc;
+      }
+      if (!big_tr.empty()) {
+        HIPCHK(hipMemcpy(w.d_big_tr, big_tr.data(), big_tr.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(w.d_off_tr, off_tr.data(), off_tr.size() * sizeof(long long), hipMemcpyHostToDevice));
+      }
+      if (!big_al.empty()) {
+        HIPCHK(hipMemcpy(w.d_big_al, big_al.data(), big_al.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(w.d_off_al, off_al.data(), off_al.size() * sizeof(long long), hipMemcpyHostToDevice));
+      }
+      HIPCHK(hipMemcpy(w.d_big_one, one.data(), sizeof(int), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(w.d_off_one, off_one.data(), sizeof(long long), hipMemcpyHostToDevice));
+    }
     if (!segs.empty())
       HIPCHK(hipMemcpy(w.d_segs, segs.data(), segs.size() * sizeof(LgdSeg), hipMemcpyHostToDevice));
   }
@@ -734,9 +787,12 @@ static int album_stage3_on(lgd_ctx *c, lgd_ctx::WorkSet &w, const double *all2, 
     w.h_album_range->n = (long long)w.lra_n;
     w.h_album_range->out = w.d_album + 1;
     HIPCHK(hipMemcpyAsync(w.d_album_range, w.h_album_range, sizeof(LgdRange), hipMemcpyHostToDevice, s));
-    HIPCHK(lgd_launch_lra(w.d_album_range, 1, w.lra_base, c->minus20, s));
+    const int big = (w.lra_n > LGD_LRA_BIG && w.lra_n <= w.lra_dist_cap) ? 1 : 0;
+    HIPCHK(lgd_launch_lra(w.d_album_range, 1, w.lra_base, c->minus20, w.d_big_one, big, w.d_lra_hist,
+                          w.d_lra_part, w.d_lra_picks, w.d_lra_cand, w.d_off_one, s));
   } else {
-    HIPCHK(lgd_launch_lra(w.d_album_ranges, n_albums, w.d_st, c->minus20, s));
+    HIPCHK(lgd_launch_lra(w.d_album_ranges, n_albums, w.d_st, c->minus20, w.d_big_al, w.n_big_al,
+                          w.d_lra_hist, w.d_lra_part, w.d_lra_picks, w.d_lra_cand, w.d_off_al, s));
   }
   return LGD_OK;
 }
@@ -823,7 +879,8 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, w.d_E, w.d_Z,
                                    w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_pmax, w.d_res, c->abs_gate,
                                    c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
-  HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, s));
+  HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, w.d_big_tr, w.n_big_tr, w.d_lra_hist,
+                        w.d_lra_part, w.d_lra_picks, w.d_lra_cand, w.d_off_tr, s));
   c->executed = true;
   if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))
     HIPCHK(lgd_launch_album_part1(w.d_res, c->d_albums, (int)c->albums.size(),

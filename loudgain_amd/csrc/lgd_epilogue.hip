@@ -271,7 +271,7 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
 
 __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__restrict__ ranges,
                                                             const double *__restrict__ st_base,
-                                                            double minus20) {
+                                                            double minus20, int skip_big) {
   LGD_EPI_PRIO();
   __shared__ double sh[LGD_LRA_NT / LGD_WAVE];
   __shared__ double cache[LGD_LRA_CAP];
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__r
   __shared__ unsigned long long s_prefix[2];
   __shared__ unsigned long long s_rank[2];
   const LgdRange rg = ranges[blockIdx.x];
+  if (skip_big && rg.n > LGD_LRA_BIG) return;  // the lgd_lra_big_* kernels take these
   const double *gv = st_base + rg.off;
   const int tid = threadIdx.x;
   const bool in_lds = rg.n <= LGD_LRA_CAP;
@@ -364,6 +365,268 @@ __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__r
     const double l_en = __longlong_as_double((long long)s_prefix[1]);
     *rg.out = energy_to_loudness(h_en) - energy_to_loudness(l_en);
   }
+}
+
+// ---- E8 for LONG lists (an album of hundreds of tracks: ~2.3e5 short-term energies in C4, where the
+// single-workgroup select above takes ~1 ms).  Same exact result, five small launches whose
+// streaming passes use LGD_LRB_WG workgroups:
+//   1 count / sum the listed energies (per-workgroup partials, folded in a fixed order) and
+//     clear the histogram
+//   2 relative threshold (-20 LU); histogram of the KEPT energies over a 16-bit digit of their
+//     bit pattern: 5 exponent bits (2^-24 .. 2^8, beyond that the end bins) + 11 mantissa bits --
+//     order preserving, ~2000 bins per octave, so the bin of a rank holds a handful of entries
+//   3 fold the histogram copies, block sums; one workgroup: the bins that hold the two ranks (index rule of libebur128:
+//     (size_t)((m - 1) * p + 0.5)) and the ranks inside them
+//   4 gather the entries of those two bins
+//   5 one workgroup: exact k-th smallest inside each (radix select on the bit patterns), LRA.
+#define LGD_LRB_WG 64
+#define LGD_LRB_NT 256   // (lgd_lra_select: one thread per 8-bit digit)
+#define LGD_LRB_BINS 65536
+#define LGD_LRB_REP 8      // copies of the histogram (equal energies would otherwise queue on one counter)
+struct LgdLraPick {
+  double integrated;           // entries < this are dropped
+  unsigned long long rank[2];  // rank inside the bin (0-based), [0] = 95 %, [1] = 10 %
+  unsigned bin[2];
+  unsigned cnt[2];             // gather counters
+  int empty, pad;
+};
+__device__ __forceinline__ unsigned lgd_lra_digit(double x) {
+  const long long b = __double_as_longlong(x) >> 41;       // exponent | top 11 mantissa bits
+  const long long d = b - ((long long)(1023 - 24) << 11);  // 2^-24 -> 0
+  return (unsigned)(d < 0 ? 0 : (d > LGD_LRB_BINS - 1 ? LGD_LRB_BINS - 1 : d));
+}
+// (ranges are indexed through big_idx: the big ranges of a range array)
+__global__ __launch_bounds__(LGD_LRB_NT) void lgd_lra_big_pass1(const LgdRange *__restrict__ ranges,
+                                                               const int *__restrict__ big_idx,
+                                                               const double *__restrict__ st_base,
+                                                               double *__restrict__ part,
+                                                               unsigned *__restrict__ hist) {
+  LGD_EPI_PRIO();
+  __shared__ double sh[LGD_LRB_NT / LGD_WAVE];
+  const LgdRange rg = ranges[big_idx[blockIdx.y]];
+  const double *gv = st_base + rg.off;
+  unsigned *h = hist + (size_t)blockIdx.y * LGD_LRB_BINS * LGD_LRB_REP;
+  for (int i = blockIdx.x * LGD_LRB_NT + threadIdx.x; i < LGD_LRB_BINS * LGD_LRB_REP; i += LGD_LRB_WG * LGD_LRB_NT)
+    h[i] = 0u;
+  const long long per = (rg.n + LGD_LRB_WG - 1) / LGD_LRB_WG;
+  const long long i0 = per * blockIdx.x, i1 = min(rg.n, i0 + per);
+  double cnt = 0.0, sum = 0.0;
+  for (long long i = i0 + threadIdx.x; i < i1; i += LGD_LRB_NT) {
+    const double x = gv[i];
+    if (x > 0.0) { cnt += 1.0; sum += x; }
+  }
+  cnt = block_sum_f64<LGD_LRB_NT>(cnt, sh);
+  sum = block_sum_f64<LGD_LRB_NT>(sum, sh);
+  if (threadIdx.x == 0) {
+    double *o = part + ((size_t)blockIdx.y * LGD_LRB_WG + blockIdx.x) * 4;
+    o[0] = cnt; o[1] = sum;
+  }
+}
+__global__ __launch_bounds__(LGD_LRB_NT) void lgd_lra_big_pass2(const LgdRange *__restrict__ ranges,
+                                                               const int *__restrict__ big_idx,
+                                                               const double *__restrict__ st_base,
+                                                               double *__restrict__ part,
+                                                               unsigned *__restrict__ hist, double minus20) {
+  LGD_EPI_PRIO();
+  __shared__ double sh[LGD_LRB_NT / LGD_WAVE];
+  const LgdRange rg = ranges[big_idx[blockIdx.y]];
+  const double *gv = st_base + rg.off;
+  unsigned *h = hist + ((size_t)blockIdx.y * LGD_LRB_REP + (blockIdx.x % LGD_LRB_REP)) * LGD_LRB_BINS;
+  double *pp = part + (size_t)blockIdx.y * LGD_LRB_WG * 4;
+  double n = 0.0, S = 0.0;
+  for (int w = 0; w < LGD_LRB_WG; ++w) { n += pp[4 * w]; S += pp[4 * w + 1]; }  // same order everywhere
+  double kept = 0.0;
+  if (n > 0.0) {
+    const double integrated = minus20 * (S / n);
+    const long long per = (rg.n + LGD_LRB_WG - 1) / LGD_LRB_WG;
+    const long long i0 = per * blockIdx.x, i1 = min(rg.n, i0 + per);
+    for (long long i = i0 + threadIdx.x; i < i1; i += LGD_LRB_NT) {
+      const double x = gv[i];
+      if (x > 0.0 && !(x < integrated)) {
+        kept += 1.0;
+        atomicAdd(&h[lgd_lra_digit(x)], 1u);
+      }
+    }
+  }
+  kept = block_sum_f64<LGD_LRB_NT>(kept, sh);
+  if (threadIdx.x == 0) pp[4 * blockIdx.x + 2] = kept;
+}
+// the LGD_LRB_REP copies of the histogram summed into copy 0; bsum[w] = entries in workgroup w's
+// LGD_LRB_BINS / LGD_LRB_WG bins
+__global__ __launch_bounds__(LGD_LRB_NT) void lgd_lra_big_fold(unsigned *__restrict__ hist,
+                                                              unsigned long long *__restrict__ bsum) {
+  LGD_EPI_PRIO();
+  __shared__ double sh[LGD_LRB_NT / LGD_WAVE];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 *h = reinterpret_cast<u32x4 *>(hist + (size_t)blockIdx.y * LGD_LRB_BINS * LGD_LRB_REP);
+  constexpr int VPW = LGD_LRB_BINS / LGD_LRB_WG / 4;  // 16-B vectors per workgroup (256)
+  static_assert(VPW == LGD_LRB_NT, "one vector of 4 bins per thread");
+  const int v = blockIdx.x * VPW + threadIdx.x;
+  u32x4 t = h[v];
+#pragma unroll
+  for (int r = 1; r < LGD_LRB_REP; ++r) t += h[(size_t)r * (LGD_LRB_BINS / 4) + v];
+  h[v] = t;
+  // (counts are < 2^32 in all, exact in a double)
+  const double tot = block_sum_f64<LGD_LRB_NT>((double)t.x + (double)t.y + (double)t.z + (double)t.w, sh);
+  if (threadIdx.x == 0) bsum[(size_t)blockIdx.y * LGD_LRB_WG + blockIdx.x] = (unsigned long long)tot;
+}
+__global__ __launch_bounds__(LGD_LRB_NT) void lgd_lra_big_pick(const LgdRange *__restrict__ ranges,
+                                                              const int *__restrict__ big_idx,
+                                                              const double *__restrict__ part,
+                                                              const unsigned *__restrict__ hist,
+                                                              const unsigned long long *__restrict__ bsum,
+                                                              LgdLraPick *__restrict__ picks, double minus20) {
+  LGD_EPI_PRIO();
+  __shared__ unsigned long long tsum[LGD_LRB_NT];
+  __shared__ int s_blk[2];
+  __shared__ unsigned long long s_before[2];
+  const LgdRange rg = ranges[big_idx[blockIdx.x]];
+  const unsigned *h = hist + (size_t)blockIdx.x * LGD_LRB_BINS * LGD_LRB_REP;  // folded copy 0
+  const unsigned long long *bs = bsum + (size_t)blockIdx.x * LGD_LRB_WG;
+  const double *pp = part + (size_t)blockIdx.x * LGD_LRB_WG * 4;
+  LgdLraPick *pk = picks + blockIdx.x;
+  double n = 0.0, S = 0.0, m = 0.0;
+  for (int w = 0; w < LGD_LRB_WG; ++w) { n += pp[4 * w]; S += pp[4 * w + 1]; m += pp[4 * w + 2]; }
+  const int tid = threadIdx.x;
+  if (n == 0.0 || m == 0.0) {
+    if (tid == 0) { *rg.out = 0.0; pk->empty = 1; pk->cnt[0] = pk->cnt[1] = 0u; }
+    return;
+  }
+  const unsigned long long r[2] = {(unsigned long long)((m - 1.0) * 0.95 + 0.5),
+                                   (unsigned long long)((m - 1.0) * 0.1 + 0.5)};
+  if (tid == 0) {
+    pk->integrated = minus20 * (S / n);
+    pk->empty = 0;
+    pk->cnt[0] = pk->cnt[1] = 0u;
+    for (int q = 0; q < 2; ++q) {  // the 1024-bin block that holds rank q
+      unsigned long long c = 0ull;
+      int w = 0;
+      while (w + 1 < LGD_LRB_WG && c + bs[w] <= r[q]) { c += bs[w]; ++w; }
+      s_blk[q] = w;
+      s_before[q] = c;
+    }
+  }
+  __syncthreads();
+  constexpr int BPB = LGD_LRB_BINS / LGD_LRB_WG;  // bins per block (1024): 4 per thread
+  for (int q = 0; q < 2; ++q) {
+    const int b0 = s_blk[q] * BPB + tid * 4;
+    const unsigned c0 = h[b0], c1 = h[b0 + 1], c2 = h[b0 + 2], c3 = h[b0 + 3];
+    __syncthreads();
+    tsum[tid] = (unsigned long long)c0 + c1 + c2 + c3;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long run = s_before[q];
+      for (int i = 0; i < LGD_LRB_NT; ++i) { const unsigned long long v = tsum[i]; tsum[i] = run; run += v; }  // exclusive
+    }
+    __syncthreads();
+    const unsigned long long lo = tsum[tid], hi = lo + c0 + c1 + c2 + c3;
+    if (lo <= r[q] && r[q] < hi) {  // exactly one thread
+      unsigned long long c = lo;
+      int b = b0;
+      const unsigned cc[4] = {c0, c1, c2, c3};
+      int j = 0;
+      while (c + cc[j] <= r[q]) { c += cc[j]; ++j; ++b; }
+      pk->bin[q] = (unsigned)b;
+      pk->rank[q] = r[q] - c;
+    }
+  }
+}
+__global__ __launch_bounds__(LGD_LRB_NT) void lgd_lra_big_gather(const LgdRange *__restrict__ ranges,
+                                                                const int *__restrict__ big_idx,
+                                                                const double *__restrict__ st_base,
+                                                                LgdLraPick *__restrict__ picks,
+                                                                double *__restrict__ cand,
+                                                                const long long *__restrict__ cand_off) {
+  LGD_EPI_PRIO();
+  const LgdRange rg = ranges[big_idx[blockIdx.y]];
+  LgdLraPick *pk = picks + blockIdx.y;
+  if (pk->empty) return;
+  const double *gv = st_base + rg.off;
+  const double integrated = pk->integrated;
+  const unsigned b0 = pk->bin[0], b1 = pk->bin[1];
+  double *c0 = cand + cand_off[blockIdx.y], *c1 = c0 + rg.n;
+  const long long per = (rg.n + LGD_LRB_WG - 1) / LGD_LRB_WG;
+  const long long i0 = per * blockIdx.x, i1 = min(rg.n, i0 + per);
+  for (long long i = i0 + threadIdx.x; i < i1; i += LGD_LRB_NT) {
+    const double x = gv[i];
+    if (x > 0.0 && !(x < integrated)) {
+      const unsigned d = lgd_lra_digit(x);
+      if (d == b0) c0[atomicAdd(&pk->cnt[0], 1u)] = x;
+      if (d == b1) c1[atomicAdd(&pk->cnt[1], 1u)] = x;
+    }
+  }
+}
+// the r-th smallest (0-based) of v[0 .. n): MSB-first radix select on the bit patterns
+#define LGD_LRB_SUB 16  // copies of the digit histogram in LDS (the entries of one bin share their top digits)
+#define LGD_LRB_STAGE 4096  // candidates staged in LDS (32 KiB); longer lists stream from L2
+__device__ double lgd_lra_select(const double *gv, unsigned n, unsigned long long r, unsigned *hist,
+                                 unsigned long long *s_state, double *stage) {
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_state[0] = 0ull; s_state[1] = r; }
+  const double *v = gv;
+  if (n <= LGD_LRB_STAGE) {
+    for (unsigned i = tid; i < n; i += LGD_LRB_NT) stage[i] = gv[i];
+    v = stage;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < 8; ++pass) {
+    const int sh_bits = 56 - 8 * pass;
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (sh_bits + 8));
+    for (int i = tid; i < 256 * LGD_LRB_SUB; i += LGD_LRB_NT) hist[i] = 0u;
+    __syncthreads();
+    const unsigned long long prefix = s_state[0];
+    for (unsigned i = tid; i < n; i += LGD_LRB_NT) {
+      const unsigned long long key = (unsigned long long)__double_as_longlong(v[i]);
+      if ((key & himask) == prefix)
+        atomicAdd(&hist[(tid % LGD_LRB_SUB) * 256 + (unsigned)((key >> sh_bits) & 0xffu)], 1u);
+    }
+    __syncthreads();
+    // the digit whose cumulative count passes the rank: thread t owns digit t (LGD_LRB_NT == 256);
+    // inclusive scan inside each wave, wave totals through LDS
+    {
+      unsigned t = 0u;
+#pragma unroll
+      for (int q = 0; q < LGD_LRB_SUB; ++q) t += hist[q * 256 + tid];
+      unsigned incl = t;
+#pragma unroll
+      for (int d = 1; d < LGD_WAVE; d <<= 1) {
+        const unsigned up = __shfl_up(incl, d, LGD_WAVE);
+        if ((tid & (LGD_WAVE - 1)) >= d) incl += up;
+      }
+      __syncthreads();
+      if ((tid & (LGD_WAVE - 1)) == LGD_WAVE - 1) hist[tid / LGD_WAVE] = incl;  // wave totals (hist is free now)
+      __syncthreads();
+      unsigned long long before = 0ull;
+      for (int w = 0; w < tid / LGD_WAVE; ++w) before += hist[w];
+      const unsigned long long rr = s_state[1];
+      const unsigned long long hi = before + incl, lo = hi - t;
+      __syncthreads();
+      if (lo <= rr && rr < hi) {  // exactly one thread
+        s_state[1] = rr - lo;
+        s_state[0] = prefix | (((unsigned long long)tid) << sh_bits);
+      }
+    }
+    __syncthreads();
+  }
+  return __longlong_as_double((long long)s_state[0]);
+}
+__global__ __launch_bounds__(LGD_LRB_NT) void lgd_lra_big_select(const LgdRange *__restrict__ ranges,
+                                                                const int *__restrict__ big_idx,
+                                                                const LgdLraPick *__restrict__ picks,
+                                                                const double *__restrict__ cand,
+                                                                const long long *__restrict__ cand_off) {
+  LGD_EPI_PRIO();
+  __shared__ unsigned hist[256 * LGD_LRB_SUB];
+  __shared__ unsigned long long s_state[2];
+  __shared__ double stage[LGD_LRB_STAGE];
+  const LgdRange rg = ranges[big_idx[blockIdx.x]];
+  const LgdLraPick pk = picks[blockIdx.x];
+  if (pk.empty) return;
+  const double *c0 = cand + cand_off[blockIdx.x], *c1 = c0 + rg.n;
+  const double h_en = lgd_lra_select(c0, pk.cnt[0], pk.rank[0], hist, s_state, stage);
+  __syncthreads();
+  const double l_en = lgd_lra_select(c1, pk.cnt[1], pk.rank[1], hist, s_state, stage);
+  if (threadIdx.x == 0) *rg.out = energy_to_loudness(h_en) - energy_to_loudness(l_en);
 }
 
 // ---- album stages (scan.c:359-405).  One workgroup per album of the plan. --------
@@ -477,11 +740,35 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
   return hipGetLastError();
 }
 
+// n_big > 0: the ranges listed in big_idx (longer than LGD_LRA_BIG) go through the multi-workgroup
+// kernels and the single-workgroup kernel skips them.  scratch: hist [n_big][8][65536] u32, part
+// [n_big][64][4] f64, picks [n_big], cand [sum 2 n_i] f64 with cand_off [n_big].
+extern "C" size_t lgd_lra_pick_bytes(void) { return sizeof(LgdLraPick); }
 extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
-                                     double minus20, hipStream_t s) {
+                                     double minus20, const int *big_idx, int n_big, unsigned *hist,
+                                     double *part, void *picks, double *cand, const long long *cand_off,
+                                     hipStream_t s) {
   if (n_ranges <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lgd_lra_kernel, dim3(n_ranges), dim3(LGD_LRA_NT), 0, s,
-                     (const LgdRange *)ranges, st_base, minus20);
+  const LgdRange *rg = (const LgdRange *)ranges;
+  if (n_big < n_ranges)
+    hipLaunchKernelGGL(lgd_lra_kernel, dim3(n_ranges), dim3(LGD_LRA_NT), 0, s, rg, st_base, minus20,
+                       n_big > 0 ? 1 : 0);
+  if (n_big > 0) {
+    hipLaunchKernelGGL(lgd_lra_big_pass1, dim3(LGD_LRB_WG, n_big), dim3(LGD_LRB_NT), 0, s, rg, big_idx, st_base,
+                       part, hist);
+    hipLaunchKernelGGL(lgd_lra_big_pass2, dim3(LGD_LRB_WG, n_big), dim3(LGD_LRB_NT), 0, s, rg, big_idx, st_base,
+                       part, hist, minus20);
+    // (block sums live behind the per-workgroup partials: part[n_big][64][4], column 3 unused -> a
+    // separate region at the end of `part`: [n_big * 256 ..) reinterpreted as 64-bit counts)
+    unsigned long long *bsum = reinterpret_cast<unsigned long long *>(part + (size_t)n_big * LGD_LRB_WG * 4);
+    hipLaunchKernelGGL(lgd_lra_big_fold, dim3(LGD_LRB_WG, n_big), dim3(LGD_LRB_NT), 0, s, hist, bsum);
+    hipLaunchKernelGGL(lgd_lra_big_pick, dim3(n_big), dim3(LGD_LRB_NT), 0, s, rg, big_idx, part, hist, bsum,
+                       (LgdLraPick *)picks, minus20);
+    hipLaunchKernelGGL(lgd_lra_big_gather, dim3(LGD_LRB_WG, n_big), dim3(LGD_LRB_NT), 0, s, rg, big_idx, st_base,
+                       (LgdLraPick *)picks, cand, cand_off);
+    hipLaunchKernelGGL(lgd_lra_big_select, dim3(n_big), dim3(LGD_LRB_NT), 0, s, rg, big_idx,
+                       (const LgdLraPick *)picks, cand, cand_off);
+  }
   return hipGetLastError();
 }
 

@@ -99,6 +99,9 @@ struct LgdRange {
   double *out;
 };
 
+// loudness-range lists longer than this take the multi-workgroup kernels (lgd_lra_big_*)
+#define LGD_LRA_BIG 8192
+
 // libebur128's default channel map by index: weight of channel
 // `ch` of an `nch`-channel stream; 0 = EBUR128_UNUSED (peaks only, e.g. LFE).
 #if defined(__HIPCC__)

@@ -477,3 +477,17 @@ def test_large_album_range_selection(scanner):
     assert abs(album["lra"] - want["lra"]) <= 1e-9
     del pcms, base
     torch.cuda.empty_cache()
+
+
+def test_long_track_range_selection(scanner, oracle):
+    """One track with more than 8192 listed 3 s blocks (2.4 h at 8 kHz mono): its own loudness range
+    goes through the multi-workgroup selection kernels (lgd_lra_big_*), like the album of a large
+    plan; same exact order statistics as the oracle's sort (ebur128_loudness_range)."""
+    rate = 8000
+    pcm = synth.track_numpy(rate * 8700, 1, rate, seed=88, step_s=41.0)
+    ref = oracle.scan_track(pcm, rate)
+    (got,), album = scanner.scan([to_dev(pcm)], rate, album=True)
+    assert got["n_st"] == ref["n_st"] and got["n_st_blocks"] > 8192 and ref["n_st"] > 1000
+    check_track(got, ref, rate=rate)
+    assert abs(got["lra"] - ref["lra"]) <= 1e-9
+    assert abs(album["lra"] - ref["lra"]) <= 1e-9 and album["n_st"] == ref["n_st"]
