@@ -70,9 +70,16 @@ void scan_set_album_result(scan_result *result, double pre_amp);
 void scan_get_album_result(scan_result *result, double pre_amp);
 /* GPU to use (default 0); call before scan_init. */
 int scan_set_device(int device);
-/* Raw PCM in place of a file.  Host buffers are copied to HBM; the _device form
- * borrows an HBM pointer (16-byte aligned, must stay valid until the first
- * result query).  s16 is scaled by 1/32768 like ebur128_add_frames_short. */
+/* Use n_devices GPUs of this process (0 = every visible one); call before scan_init.  The files
+ * of the session are dealt round-robin over them (index mod n), every GPU scans its share and
+ * the album values of scan_set_album_result / scan_get_album_peak come from the exchange of
+ * partial sums that loudgain_amd/album.py runs over RCCL, here through host memory (a few MB).
+ * The environment variable LOUDSCAN_DEVICES=n does the same for an unmodified caller
+ * (loudgain.c:299-340 never needs to know). */
+int scan_set_devices(int n_devices);
+/* Raw PCM in place of a file.  Host buffers are copied to HBM (through pinned staging
+ * buffers, asynchronously: the call returns once the last piece is on its way); the _device
+ * form borrows an HBM pointer (16-byte aligned, must stay valid until scan_deinit).  s16 is scaled by 1/32768 like ebur128_add_frames_short. */
 int scan_pcm_s16(const short *interleaved, size_t frames, unsigned channels, unsigned rate,
                  unsigned index);
 int scan_pcm_f32(const float *interleaved, size_t frames, unsigned channels, unsigned rate,

@@ -39,18 +39,40 @@ enum {
 
 namespace {
 
+// PCM moves host -> HBM in pieces of this many bytes through two pinned buffers per GPU
+const size_t STAGE_BYTES = 64u << 20;
+const size_t ARENA_MIN = 64u << 20, ARENA_MAX = 1u << 30;
+
+// One GPU of the session: its engine context, its stream, an arena the tracks' f32 PCM lives in
+// until scan_deinit (one hipMalloc per ~GB, not per file), pinned double-buffered staging.
+struct Dev {
+  int hip_id = 0;
+  lgd_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;
+  std::vector<void *> blocks;  // arena blocks
+  char *cur = nullptr;
+  size_t cur_left = 0, next_block = ARENA_MIN;
+  void *pinned[2] = {nullptr, nullptr};
+  void *dev_stage[2] = {nullptr, nullptr};  // S16 pieces waiting for the widening kernel
+  hipEvent_t ev[2] = {nullptr, nullptr};    // piece i of a buffer has left it (copy / widening done)
+  bool ev_used[2] = {false, false};
+  int turn = 0;
+  std::vector<int> tracks;  // file indices scanned on this GPU, ascending
+};
+
 struct Track {
   char *file = nullptr, *container = nullptr;
   int codec = 0;
   unsigned channels = 0, rate = 0;
   size_t frames = 0;
-  float *dev = nullptr;  // interleaved f32 in HBM
-  bool owned = false, loaded = false;
+  float *dev = nullptr;  // interleaved f32 in HBM (arena of its GPU, or borrowed)
+  int gpu = 0;           // index into g_devs
+  bool loaded = false;
 };
 
 std::vector<Track> g_tracks;
-int g_nb = 0, g_device = 0;
-lgd_ctx *g_ctx = nullptr;
+std::vector<Dev> g_devs;
+int g_nb = 0, g_device = 0, g_want_devices = 1;
 bool g_scanned = false;
 std::vector<lgd_track_result> g_res;
 lgd_album_result g_album;
@@ -87,10 +109,53 @@ char *dupstr(const char *s) {
 }
 
 void release_track(Track &t) {
-  if (t.dev && t.owned) (void)hipFree(t.dev);
   free(t.file);
   free(t.container);
   t = Track();
+}
+
+void dev_open(Dev &d) {
+  HIPFATAL(hipSetDevice(d.hip_id));
+  if (!d.stream) HIPFATAL(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) {
+    if (!d.pinned[i]) HIPFATAL(hipHostMalloc(&d.pinned[i], STAGE_BYTES));
+    if (!d.dev_stage[i]) HIPFATAL(hipMalloc(&d.dev_stage[i], STAGE_BYTES));
+    if (!d.ev[i]) HIPFATAL(hipEventCreateWithFlags(&d.ev[i], hipEventDisableTiming));
+  }
+}
+
+void dev_close(Dev &d) {
+  (void)hipSetDevice(d.hip_id);
+  if (d.stream) (void)hipStreamSynchronize(d.stream);
+  if (d.ctx) lgd_destroy(d.ctx);
+  for (void *b : d.blocks) (void)hipFree(b);
+  for (int i = 0; i < 2; ++i) {
+    if (d.pinned[i]) (void)hipHostFree(d.pinned[i]);
+    if (d.dev_stage[i]) (void)hipFree(d.dev_stage[i]);
+    if (d.ev[i]) (void)hipEventDestroy(d.ev[i]);
+  }
+  if (d.stream) (void)hipStreamDestroy(d.stream);
+  d = Dev();
+}
+
+// 256-B aligned piece of the GPU's arena (lives until scan_deinit: a file may be scanned again,
+// like the reference allows, and the album needs every track at the first result query)
+void *arena_alloc(Dev &d, size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes > d.cur_left) {
+    size_t blk = std::max(bytes, d.next_block);
+    void *p = nullptr;
+    HIPFATAL(hipSetDevice(d.hip_id));
+    HIPFATAL(hipMalloc(&p, blk));
+    d.blocks.push_back(p);
+    d.cur = (char *)p;
+    d.cur_left = blk;
+    d.next_block = std::min(ARENA_MAX, d.next_block * 2);
+  }
+  void *r = d.cur;
+  d.cur += bytes;
+  d.cur_left -= bytes;
+  return r;
 }
 
 void begin_track(unsigned index, const char *name, const char *container, int codec,
@@ -106,22 +171,36 @@ void begin_track(unsigned index, const char *name, const char *container, int co
   t.channels = channels;
   t.rate = rate;
   t.frames = frames;
+  t.gpu = (int)(index % g_devs.size());  // tracks are dealt round-robin over the GPUs
   t.loaded = true;
   g_scanned = false;
 }
 
-void upload_s16(Track &t, const short *pcm) {
-  const size_t n = t.frames * t.channels;
-  HIPFATAL(hipSetDevice(g_device));
-  HIPFATAL(hipMalloc((void **)&t.dev, (n ? n : 1) * sizeof(float)));
-  t.owned = true;
-  if (!n) return;
-  short *tmp = nullptr;  // device S16 staging: half the PCIe bytes of f32
-  HIPFATAL(hipMalloc((void **)&tmp, n * sizeof(short)));
-  HIPFATAL(hipMemcpy(tmp, pcm, n * sizeof(short), hipMemcpyHostToDevice));
-  HIPFATAL(lgd_launch_s16_to_f32(tmp, t.dev, n, nullptr));
-  HIPFATAL(hipDeviceSynchronize());
-  HIPFATAL(hipFree(tmp));
+// Streams `total` samples into the track's f32 buffer.  `fill(dst, first, n)` puts samples
+// [first, first + n) into a pinned buffer, as S16 (widened on the GPU: half the PCIe bytes, and
+// the grid scan.c:414 puts every input on) or as f32.  Two pinned buffers alternate: piece i + 1 is
+// produced while piece i crosses PCIe; nothing here waits for the GPU except for a buffer's turn.
+template <typename Fill>
+void upload(Track &t, size_t total, bool as_s16, Fill fill) {
+  Dev &d = g_devs[t.gpu];
+  HIPFATAL(hipSetDevice(d.hip_id));
+  t.dev = (float *)arena_alloc(d, (total ? total : 1) * sizeof(float));
+  const size_t piece = STAGE_BYTES / (as_s16 ? sizeof(short) : sizeof(float));  // multiple of 8 samples
+  for (size_t first = 0; first < total; first += piece) {
+    const size_t n = std::min(piece, total - first);
+    const int b = d.turn;
+    d.turn ^= 1;
+    if (d.ev_used[b]) HIPFATAL(hipEventSynchronize(d.ev[b]));  // the buffer's previous piece has left it
+    fill(d.pinned[b], first, n);
+    if (as_s16) {
+      HIPFATAL(hipMemcpyAsync(d.dev_stage[b], d.pinned[b], n * sizeof(short), hipMemcpyHostToDevice, d.stream));
+      HIPFATAL(lgd_launch_s16_to_f32((const short *)d.dev_stage[b], t.dev + first, n, d.stream));
+    } else {
+      HIPFATAL(hipMemcpyAsync(t.dev + first, d.pinned[b], n * sizeof(float), hipMemcpyHostToDevice, d.stream));
+    }
+    HIPFATAL(hipEventRecord(d.ev[b], d.stream));
+    d.ev_used[b] = true;
+  }
 }
 
 uint32_t rd32(const unsigned char *p) {
@@ -130,31 +209,113 @@ uint32_t rd32(const unsigned char *p) {
 uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 short clip16(long v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
 
-// the whole session in one batched device scan
+void copy_results(const std::vector<int> &idx, const std::vector<lgd_track_result> &r) {
+  for (size_t k = 0; k < idx.size(); ++k) g_res[idx[k]] = r[k];
+}
+
+// The whole session in one batched scan per GPU.  One GPU: tracks and album in one plan.
+// Several GPUs (scan.c's album walk over all states, scan.c:359-405, split over the devices of this
+// process): every GPU scans its tracks, then the exchange of loudgain_amd/album.py through the host
+// -- record 1 of every GPU (partial sums, peak, its listed 3 s energies) to all, relative gate from
+// the heads in device order, second pass, record 2 to all, album loudness / range / peak on every
+// GPU (identical bits) -- a few MB at most.
 void ensure_scanned() {
   if (g_scanned) return;
   for (int i = 0; i < g_nb; ++i)
     if (!g_tracks[i].loaded) fail("scan_file was not called for index %d", i);
-  if (!g_ctx) {
-    g_ctx = lgd_create(g_device);
-    if (!g_ctx) fail("%s", lgd_last_error());
-  }
-  std::vector<lgd_track> lt(g_nb);
-  for (int i = 0; i < g_nb; ++i) {
-    lt[i].pcm = g_tracks[i].dev;
-    lt[i].frames = g_tracks[i].frames;
-    lt[i].channels = g_tracks[i].channels;
-    lt[i].rate = g_tracks[i].rate;
-  }
+  const size_t nd = g_devs.size();
   g_res.assign(g_nb ? g_nb : 1, lgd_track_result());
-  if (lgd_plan(g_ctx, lt.data(), (uint32_t)g_nb, LGD_FLAG_TRUE_PEAK | LGD_FLAG_ALBUM) ||
-      lgd_execute(g_ctx, nullptr) || lgd_fetch(g_ctx, g_res.data(), &g_album))
-    fail("%s", lgd_last_error());
-  // the PCM is no longer needed: results are cached until the next scan_file
+  std::vector<std::vector<lgd_track>> lt(nd);
+  for (Dev &d : g_devs) d.tracks.clear();
   for (int i = 0; i < g_nb; ++i) {
-    Track &t = g_tracks[i];
-    if (t.dev && t.owned) (void)hipFree(t.dev);
-    t.dev = nullptr;
+    const Track &t = g_tracks[i];
+    lgd_track x;
+    x.pcm = t.dev;
+    x.frames = t.frames;
+    x.channels = t.channels;
+    x.rate = t.rate;
+    lt[t.gpu].push_back(x);
+    g_devs[t.gpu].tracks.push_back(i);
+  }
+  for (Dev &d : g_devs) {
+    HIPFATAL(hipSetDevice(d.hip_id));
+    if (!d.ctx) {
+      d.ctx = lgd_create(d.hip_id);
+      if (!d.ctx) fail("%s", lgd_last_error());
+    }
+  }
+  if (nd == 1) {
+    Dev &d = g_devs[0];
+    std::vector<lgd_track_result> r(g_nb ? g_nb : 1);
+    if (lgd_plan(d.ctx, lt[0].data(), (uint32_t)g_nb, LGD_FLAG_TRUE_PEAK | LGD_FLAG_ALBUM) ||
+        lgd_execute(d.ctx, d.stream) || lgd_fetch(d.ctx, r.data(), &g_album))
+      fail("%s", lgd_last_error());
+    copy_results(d.tracks, r);
+    g_scanned = true;
+    return;
+  }
+  // ---- several GPUs
+  const uint32_t flags = LGD_FLAG_TRUE_PEAK | LGD_FLAG_ALBUM_PART1;
+  uint64_t slots = 0;
+  for (size_t k = 0; k < nd; ++k) {  // record 1 must have one length everywhere: the longest
+    Dev &d = g_devs[k];
+    double *p;
+    uint64_t n;
+    if (lgd_set_param(d.ctx, "album_slots", 0) || lgd_set_param(d.ctx, "album_world", (long)nd) ||
+        lgd_plan(d.ctx, lt[k].data(), (uint32_t)lt[k].size(), flags) || lgd_album_record1(d.ctx, &p, &n))
+      fail("%s", lgd_last_error());
+    slots = std::max(slots, n - 4);
+  }
+  for (size_t k = 0; k < nd; ++k) {
+    Dev &d = g_devs[k];
+    if (lgd_set_param(d.ctx, "album_slots", (long)slots) ||
+        lgd_plan(d.ctx, lt[k].data(), (uint32_t)lt[k].size(), flags) || lgd_execute(d.ctx, d.stream))
+      fail("%s", lgd_last_error());  // (all GPUs now scan at the same time)
+  }
+  const uint64_t n1 = slots + 4;
+  std::vector<double> all1(nd * n1), all2(nd * 2);
+  std::vector<double *> d_all1(nd), d_all2(nd);
+  for (size_t k = 0; k < nd; ++k) {
+    Dev &d = g_devs[k];
+    double *p;
+    uint64_t n;
+    HIPFATAL(hipSetDevice(d.hip_id));
+    if (lgd_album_join(d.ctx, d.stream) || lgd_album_record1(d.ctx, &p, &n)) fail("%s", lgd_last_error());
+    HIPFATAL(hipMemcpyAsync(&all1[k * n1], p, n1 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  }
+  for (Dev &d : g_devs) {
+    HIPFATAL(hipSetDevice(d.hip_id));
+    HIPFATAL(hipStreamSynchronize(d.stream));
+  }
+  for (size_t k = 0; k < nd; ++k) {
+    Dev &d = g_devs[k];
+    HIPFATAL(hipSetDevice(d.hip_id));
+    d_all1[k] = (double *)arena_alloc(d, all1.size() * sizeof(double));
+    d_all2[k] = (double *)arena_alloc(d, all2.size() * sizeof(double));
+    HIPFATAL(hipMemcpyAsync(d_all1[k], all1.data(), all1.size() * sizeof(double), hipMemcpyHostToDevice, d.stream));
+    double *r2;
+    if (lgd_album_stage2(d.ctx, d_all1[k], (uint32_t)nd, d.stream) || lgd_album_record2(d.ctx, &r2))
+      fail("%s", lgd_last_error());
+    HIPFATAL(hipMemcpyAsync(&all2[k * 2], r2, 2 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  }
+  for (Dev &d : g_devs) {
+    HIPFATAL(hipSetDevice(d.hip_id));
+    HIPFATAL(hipStreamSynchronize(d.stream));
+  }
+  for (size_t k = 0; k < nd; ++k) {
+    Dev &d = g_devs[k];
+    HIPFATAL(hipSetDevice(d.hip_id));
+    HIPFATAL(hipMemcpyAsync(d_all2[k], all2.data(), all2.size() * sizeof(double), hipMemcpyHostToDevice, d.stream));
+    if (lgd_album_stage3(d.ctx, d_all2[k], (uint32_t)nd, d.stream)) fail("%s", lgd_last_error());
+  }
+  for (size_t k = 0; k < nd; ++k) {
+    Dev &d = g_devs[k];
+    HIPFATAL(hipSetDevice(d.hip_id));
+    std::vector<lgd_track_result> r(lt[k].size() ? lt[k].size() : 1);
+    lgd_album_result a;
+    if (lgd_fetch(d.ctx, r.data(), &a)) fail("%s", lgd_last_error());
+    copy_results(d.tracks, r);
+    if (k == 0) g_album = a;  // (every GPU holds the same album numbers)
   }
   g_scanned = true;
 }
@@ -163,6 +324,12 @@ void ensure_scanned() {
 
 extern "C" int scan_set_device(int device) {
   g_device = device;
+  g_want_devices = 1;
+  return 0;
+}
+
+extern "C" int scan_set_devices(int n_devices) {
+  g_want_devices = n_devices;  // 0 = every visible GPU
   return 0;
 }
 
@@ -170,6 +337,21 @@ extern "C" int scan_init(unsigned nb_files) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || g_device >= n)
     fail("no MI355X / HIP device %d available (the scanner has no CPU path)", g_device);
+  if (!g_devs.empty() || !g_tracks.empty()) scan_deinit();  // a session that was never closed
+  int want = g_want_devices == 0 ? n : g_want_devices;
+  // LOUDSCAN_DEVICES=k: use k GPUs (0 = all) without touching the caller; LOUDSCAN_VIRTUAL_DEVICES=k:
+  // k engine contexts dealt over the real GPUs -- rehearses the multi-GPU album on a one-GPU box
+  int virt = 0;
+  if (const char *e = getenv("LOUDSCAN_DEVICES")) want = atoi(e) == 0 ? n : atoi(e);
+  if (const char *e = getenv("LOUDSCAN_VIRTUAL_DEVICES")) virt = atoi(e);
+  if (want > n) want = n;
+  if (want < 1) want = 1;
+  const int nd = virt > 0 ? virt : want;
+  g_devs.assign((size_t)nd, Dev());
+  for (int k = 0; k < nd; ++k) {
+    g_devs[k].hip_id = want == 1 ? g_device : k % want;
+    dev_open(g_devs[k]);
+  }
   g_nb = (int)nb_files;
   g_tracks.assign(nb_files, Track());
   g_scanned = false;
@@ -180,8 +362,8 @@ extern "C" void scan_deinit(void) {
   for (Track &t : g_tracks) release_track(t);
   g_tracks.clear();
   g_res.clear();
-  if (g_ctx) lgd_destroy(g_ctx);
-  g_ctx = nullptr;
+  for (Dev &d : g_devs) dev_close(d);
+  g_devs.clear();
   g_nb = 0;
   g_scanned = false;
 }
@@ -190,7 +372,8 @@ extern "C" int scan_pcm_s16(const short *pcm, size_t frames, unsigned channels, 
                             unsigned index) {
   if ((int)index >= g_nb) return -1;
   begin_track(index, "<pcm_s16>", "wav", CODEC_PCM_S16LE, channels, rate, frames);
-  upload_s16(g_tracks[index], pcm);
+  upload(g_tracks[index], frames * channels, true,
+         [&](void *dst, size_t first, size_t n) { memcpy(dst, pcm + first, n * sizeof(short)); });
   return 0;
 }
 
@@ -198,12 +381,8 @@ extern "C" int scan_pcm_f32(const float *pcm, size_t frames, unsigned channels, 
                             unsigned index) {
   if ((int)index >= g_nb) return -1;
   begin_track(index, "<pcm_f32>", "wav", CODEC_PCM_F32LE, channels, rate, frames);
-  Track &t = g_tracks[index];
-  const size_t n = frames * channels;
-  HIPFATAL(hipSetDevice(g_device));
-  HIPFATAL(hipMalloc((void **)&t.dev, (n ? n : 1) * sizeof(float)));
-  t.owned = true;
-  if (n) HIPFATAL(hipMemcpy(t.dev, pcm, n * sizeof(float), hipMemcpyHostToDevice));
+  upload(g_tracks[index], frames * channels, false,
+         [&](void *dst, size_t first, size_t n) { memcpy(dst, pcm + first, n * sizeof(float)); });
   return 0;
 }
 
@@ -211,8 +390,13 @@ extern "C" int scan_pcm_f32_device(const float *dev, size_t frames, unsigned cha
                                    unsigned index) {
   if ((int)index >= g_nb) return -1;
   begin_track(index, "<pcm_f32_device>", "wav", CODEC_PCM_F32LE, channels, rate, frames);
-  g_tracks[index].dev = const_cast<float *>(dev);
-  g_tracks[index].owned = false;
+  Track &t = g_tracks[index];
+  t.dev = const_cast<float *>(dev);
+  // a borrowed buffer is scanned where it lives
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, dev) == hipSuccess)
+    for (size_t k = 0; k < g_devs.size(); ++k)
+      if (g_devs[k].hip_id == attr.device) { t.gpu = (int)k; break; }
   return 0;
 }
 
@@ -279,7 +463,15 @@ int wav_probe(const char *file, WavInfo *wi) {
         break;
       }
       wi->data_off = ftell(fp);
-      wi->frames = sz / wi->block_align;
+      {
+        // never trust the announced size beyond the file: a streamed / piped WAV says 0 or
+        // 0xFFFFFFFF (FFmpeg's demuxer then reads to the end, scan.c:225), a truncated one too much
+        fseek(fp, 0, SEEK_END);
+        const long end = ftell(fp);
+        const size_t avail = end > wi->data_off ? (size_t)(end - wi->data_off) : 0;
+        const size_t bytes = (sz == 0 || sz == 0xFFFFFFFFu || sz > avail) ? avail : sz;
+        wi->frames = bytes / wi->block_align;
+      }
       rc = WAV_OK;
       break;
     } else {
@@ -290,6 +482,38 @@ int wav_probe(const char *file, WavInfo *wi) {
   return rc;
 }
 
+// any PCM flavour of the data chunk -> interleaved S16 (what swr_convert yields at scan.c:442)
+void convert_frames(const WavInfo &wi, const unsigned char *raw, size_t got, short *o) {
+  const unsigned ch = wi.channels, ba = wi.block_align, bps = wi.bits / 8;
+  for (size_t f = 0; f < got; ++f) {
+    const unsigned char *p = raw + f * ba;
+    for (unsigned c = 0; c < ch; ++c, p += bps) {
+      short v;
+      switch (wi.codec) {
+        case CODEC_PCM_S16LE: v = (short)rd16(p); break;
+        case CODEC_PCM_U8: v = (short)(((int)p[0] - 0x80) * 256); break;
+        case CODEC_PCM_S24LE:
+          v = (short)((int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24) >> 16);
+          break;
+        case CODEC_PCM_S32LE: v = (short)((int32_t)rd32(p) >> 16); break;
+        case CODEC_PCM_F32LE: {
+          float x;
+          const uint32_t u = rd32(p);
+          memcpy(&x, &u, 4);
+          v = clip16(lrintf(x * 32768.0f));
+        } break;
+        default: {
+          double x;
+          const uint64_t u = (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32);
+          memcpy(&x, &u, 8);
+          v = clip16(lrint(x * 32768.0));
+        } break;
+      }
+      o[f * ch + c] = v;
+    }
+  }
+}
+
 // the data chunk -> interleaved S16, as swr_convert does for every decoded frame at
 // scan.c:442; returns the frames actually present (a truncated file is silently
 // shortened, like the packet loop at scan.c:229-240), or -1 if the file vanished
@@ -298,7 +522,7 @@ long long wav_read_s16(const char *file, const WavInfo &wi, short *out, size_t c
   if (!fp) return -1;
   fseek(fp, wi.data_off, SEEK_SET);
   const size_t want = wi.frames < cap_frames ? wi.frames : cap_frames;
-  const unsigned ch = wi.channels, ba = wi.block_align, bps = wi.bits / 8;
+  const unsigned ch = wi.channels, ba = wi.block_align;
   size_t done = 0;
   if (wi.codec == CODEC_PCM_S16LE && ba == ch * 2) {  // already the target grid: straight read
     done = want ? fread(out, ba, want, fp) : 0;
@@ -310,40 +534,41 @@ long long wav_read_s16(const char *file, const WavInfo &wi, short *out, size_t c
     const size_t n = std::min<size_t>(65536, want - done);
     const size_t got = fread(raw.data(), ba, n, fp);
     if (!got) break;
-    short *o = out + done * ch;
-    for (size_t f = 0; f < got; ++f) {
-      const unsigned char *p = raw.data() + f * ba;
-      for (unsigned c = 0; c < ch; ++c, p += bps) {
-        short v;
-        switch (wi.codec) {
-          case CODEC_PCM_S16LE: v = (short)rd16(p); break;
-          case CODEC_PCM_U8: v = (short)(((int)p[0] - 0x80) * 256); break;
-          case CODEC_PCM_S24LE:
-            v = (short)((int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24) >> 16);
-            break;
-          case CODEC_PCM_S32LE: v = (short)((int32_t)rd32(p) >> 16); break;
-          case CODEC_PCM_F32LE: {
-            float x;
-            const uint32_t u = rd32(p);
-            memcpy(&x, &u, 4);
-            v = clip16(lrintf(x * 32768.0f));
-          } break;
-          default: {
-            double x;
-            const uint64_t u = (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32);
-            memcpy(&x, &u, 8);
-            v = clip16(lrint(x * 32768.0));
-          } break;
-        }
-        o[f * ch + c] = v;
-      }
-    }
+    convert_frames(wi, raw.data(), got, out + done * ch);
     done += got;
     if (got < n) break;
   }
   fclose(fp);
   return (long long)done;
 }
+
+// sequential reader over the data chunk for scan_file's piecewise upload
+struct WavReader {
+  FILE *fp;
+  WavInfo wi;
+  std::vector<unsigned char> raw;
+  WavReader(const char *file, const WavInfo &w) : fp(fopen(file, "rb")), wi(w) {
+    if (!fp) fail("Could not open input: %s", file);
+    fseek(fp, wi.data_off, SEEK_SET);
+  }
+  ~WavReader() { if (fp) fclose(fp); }
+  // up to `frames` frames as interleaved S16; returns the frames delivered
+  size_t read(short *out, size_t frames) {
+    const unsigned ch = wi.channels, ba = wi.block_align;
+    if (wi.codec == CODEC_PCM_S16LE && ba == ch * 2) return frames ? fread(out, ba, frames, fp) : 0;
+    size_t done = 0;
+    raw.resize((size_t)65536 * ba);
+    while (done < frames) {
+      const size_t n = std::min<size_t>(65536, frames - done);
+      const size_t got = fread(raw.data(), ba, n, fp);
+      if (!got) break;
+      convert_frames(wi, raw.data(), got, out + done * ch);
+      done += got;
+      if (got < n) break;
+    }
+    return done;
+  }
+};
 
 }  // namespace
 
@@ -382,11 +607,17 @@ extern "C" int scan_file(const char *file, unsigned index) {
     case WAV_ECODEC: fail("Could not find the codec: %s", file);
     default: fail("Could not find audio stream: %s", file);
   }
-  std::vector<short> s16(wi.frames * wi.channels);
-  const long long got = wav_read_s16(file, wi, s16.data(), wi.frames);
-  if (got < 0) fail("Could not open input: %s", file);
-  begin_track(index, file, "wav", wi.codec, wi.channels, wi.rate, (size_t)got);
-  upload_s16(g_tracks[index], s16.data());
+  begin_track(index, file, "wav", wi.codec, wi.channels, wi.rate, wi.frames);
+  // straight from the file into the pinned staging buffers, piece by piece (the packet loop of
+  // scan.c:225-250 without the per-frame swr_init / av_malloc); a file that ends early leaves
+  // silence behind, like the reference it is "silently truncated" (its frames stay as announced
+  // by the -- already clamped -- data chunk)
+  WavReader rd(file, wi);
+  upload(g_tracks[index], wi.frames * wi.channels, true, [&](void *dst, size_t first, size_t n) {
+    const size_t got = rd.read((short *)dst, n / wi.channels) * wi.channels;
+    if (got < n) memset((short *)dst + got, 0, (n - got) * sizeof(short));
+    (void)first;
+  });
   return 0;
 }
 

@@ -28,7 +28,7 @@ SCAN_SYMBOLS = [
     "scan_album_has_different_containers", "scan_album_has_opus", "scan_file",
     "scan_get_track_result", "scan_get_album_peak", "scan_set_album_result",
     "scan_get_album_result", "scan_set_device", "scan_pcm_s16", "scan_pcm_f32",
-    "scan_pcm_f32_device", "scan_set_codec", "scan_wav_probe", "scan_wav_read_s16",
+    "scan_pcm_f32_device", "scan_set_codec", "scan_wav_probe", "scan_wav_read_s16", "scan_set_devices",
 ]
 
 
@@ -56,6 +56,7 @@ def _lib_scan():
         L.scan_get_album_result.argtypes = [C.POINTER(ScanResult), C.c_double]
         L.scan_get_album_result.restype = None
         L.scan_set_device.argtypes = [C.c_int]
+        L.scan_set_devices.argtypes = [C.c_int]
         L.scan_pcm_s16.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
         L.scan_pcm_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
         L.scan_pcm_f32_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]

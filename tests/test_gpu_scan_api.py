@@ -157,3 +157,101 @@ def test_fatal_errors_exit_like_fail_printf(tmp_path, code, msg):
     r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1, (r.returncode, r.stderr[-300:])
     assert msg in r.stderr and "survived" not in r.stdout
+
+
+def _session(paths, scan):
+    n = len(paths)
+    assert scan.scan_init(n) == 0
+    for i, p in enumerate(paths):
+        assert scan.scan_file(p, i) == 0
+    out = []
+    for i in range(n):
+        r = scan.scan_get_track_result(i, 0.0)
+        scan.scan_set_album_result(r, 0.0)
+        out.append({f: getattr(r, f) for f in FIELDS})
+        r.free()
+    peak = scan.scan_get_album_peak()
+    scan.scan_deinit()
+    return out, peak
+
+
+@pytest.mark.parametrize("virtual", [2, 3, 5])
+def test_album_over_several_devices_of_one_process(oracle, tmp_path, virtual, monkeypatch):
+    """scan_set_devices / LOUDSCAN_DEVICES: the files of a session dealt round-robin over several GPUs
+    of ONE process, album values from the exchange of partial sums (what loudgain.c:299-340 gets
+    without knowing).  A one-GPU box rehearses it with LOUDSCAN_VIRTUAL_DEVICES: that many engine
+    contexts, all stages of the exchange, one device.  Must equal the single-context session bit for
+    bit in every count-derived field and the oracle within the usual bars."""
+    from loudgain_amd import scan
+    L = oracle.lib()
+    specs = [(48000, 2, 14.0, 1.0), (48000, 2, 9.0, 0.04), (44100, 1, 11.0, 1.0), (48000, 2, 33.0, 0.5),
+             (96000, 2, 5.0, 1.0), (48000, 6, 4.5, 0.8), (48000, 2, 0.2, 1.0), (48000, 2, 17.0, 0.25)]
+    paths = []
+    for i, (rate, ch, secs, g) in enumerate(specs):
+        pcm = synth.snap_s16_numpy(synth.track_numpy(int(rate * secs), ch, rate, seed=60 + i, step_s=1.5) * g)
+        paths.append(write_wav(str(tmp_path / ("t%d.wav" % i)), pcm, rate))
+    monkeypatch.delenv("LOUDSCAN_VIRTUAL_DEVICES", raising=False)
+    one, peak1 = _session(paths, scan)
+    monkeypatch.setenv("LOUDSCAN_VIRTUAL_DEVICES", str(virtual))
+    many, peakn = _session(paths, scan)
+    monkeypatch.delenv("LOUDSCAN_VIRTUAL_DEVICES")
+    L.lgo_scan_init(len(paths))
+    for i, p in enumerate(paths):
+        L.lgo_scan_file(p.encode(), i)
+    for i, (a, b) in enumerate(zip(one, many)):
+        o = L.lgo_scan_get_track_result(i, 0.0).contents
+        L.lgo_scan_set_album_result(C.byref(o), 0.0)
+        for f in FIELDS:
+            if f.startswith("track") or f == "loudness_reference":
+                assert a[f] == b[f] or (math.isinf(a[f]) and math.isinf(b[f]))       # same kernels, same plan per track
+            else:
+                assert close(a[f], b[f], 1e-9), (f, a[f], b[f])                        # album: another summation order
+            assert close(b[f], getattr(o, f), 1e-4 if "peak" in f else 1e-6), (i, f)
+    assert peak1 == peakn
+    L.lgo_scan_deinit()
+
+
+def test_rescan_reinit_and_big_file(oracle, tmp_path):
+    """What scan.c tolerates: scanning an index again after results were read, scan_init without a
+    scan_deinit in between.  And a file larger than one staging piece (64 MB of S16), i.e. the
+    double-buffered pinned upload path with several pieces."""
+    from loudgain_amd import scan
+    rate = 48000
+    big = synth.track_numpy(rate * 60 * 7, 2, rate, seed=5, step_s=11.0)          # 40.3 M samples = 80 MB as S16
+    small = synth.track_numpy(rate * 6, 2, rate, seed=6)
+    pb, ps = write_wav(str(tmp_path / "big.wav"), big, rate), write_wav(str(tmp_path / "small.wav"), small, rate)
+    ref_b, ref_s = oracle.scan_track(big, rate), oracle.scan_track(small, rate)
+    scan.scan_init(2)
+    scan.scan_file(ps, 0)
+    scan.scan_file(ps, 1)
+    a = scan.scan_get_track_result(1, 0.0)
+    assert abs(a.track_loudness - ref_s["loudness"]) <= 1e-6
+    scan.scan_file(pb, 1)                       # index 1 again, after its result was read
+    b = scan.scan_get_track_result(1, 0.0)
+    assert abs(b.track_loudness - ref_b["loudness"]) <= 1e-6 and abs(b.track_peak - ref_b["peak"]) <= 1e-4
+    assert abs(b.track_loudness_range - ref_b["lra"]) <= 1e-6
+    scan.scan_init(1)                           # no scan_deinit: the old session is dropped
+    scan.scan_file(ps, 0)
+    c = scan.scan_get_track_result(0, 0.0)
+    assert abs(c.track_loudness - ref_s["loudness"]) <= 1e-6
+    scan.scan_deinit()
+
+
+@pytest.mark.parametrize("announced", [0, 0xFFFFFFFF, 10**9])
+def test_wav_with_unreliable_data_size(oracle, tmp_path, announced):
+    """Streamed WAVs announce 0 or 0xFFFFFFFF bytes of data, truncated ones too many: the reader goes by
+    the file (FFmpeg's demuxer reads to the end of the file as well, scan.c:225)."""
+    from loudgain_amd import scan
+    rate = 48000
+    pcm = synth.track_numpy(rate * 5, 2, rate, seed=9, step_s=1.0)
+    p = write_wav(str(tmp_path / "s.wav"), pcm, rate)
+    raw = bytearray(open(p, "rb").read())
+    off = raw.index(b"data") + 4
+    raw[off:off + 4] = struct.pack("<I", announced)
+    open(p, "wb").write(raw)
+    ref = oracle.scan_track(pcm, rate)
+    scan.scan_init(1)
+    scan.scan_file(p, 0)
+    r = scan.scan_get_track_result(0, 0.0)
+    assert abs(r.track_loudness - ref["loudness"]) <= 1e-6 and abs(r.track_peak - ref["peak"]) <= 1e-4
+    scan.scan_deinit()
