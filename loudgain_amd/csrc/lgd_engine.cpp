@@ -232,7 +232,7 @@ static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at m
 struct lgd_ctx {
   int device = 0;
   long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 0,
-       p_album_slots = 0, p_tp_prune = 1, p_album_world = 8;
+       p_album_slots = 0, p_tp_prune = 1, p_album_world = 8, p_group_streams = 0;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -287,6 +287,10 @@ struct lgd_ctx {
   int cur_set = 0;    // set of the last lgd_execute
   hipStream_t side = nullptr;
   hipEvent_t ev_join = nullptr;  // lgd_join: end of the internal stream's work so far
+  static const int GSTREAMS = 3;   // extra streams the groups of a mixed plan are launched on
+  hipStream_t gstream[GSTREAMS] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_gjoin[GSTREAMS] = {nullptr, nullptr, nullptr};
+  std::vector<size_t> group_order;  // launch order of the groups: largest first
   LgdSlice *d_slices = nullptr;
   LgdFilt *d_filt = nullptr;  // [MAX_GROUPS] per-group kernel constants
   LgdTrackMeta *d_meta = nullptr;
@@ -344,6 +348,11 @@ extern "C" lgd_ctx *lgd_create(int device) {
   }
   ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < lgd_ctx::GSTREAMS; ++i) {
+    ok = ok && hipStreamCreateWithFlags(&c->gstream[i], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_gjoin[i], hipEventDisableTiming) == hipSuccess;
+  }
   ok = ok && hipMalloc((void **)&c->d_filt, MAX_GROUPS * sizeof(LgdFilt)) == hipSuccess;
   if (!ok) {
     fail(LGD_ENOMEM, "lgd_create: allocation failed");
@@ -374,6 +383,11 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
     if (p) (void)hipFree(p);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (int i = 0; i < lgd_ctx::GSTREAMS; ++i) {
+    if (c->gstream[i]) (void)hipStreamDestroy(c->gstream[i]);
+    if (c->ev_gjoin[i]) (void)hipEventDestroy(c->ev_gjoin[i]);
+  }
   for (int i = 0; i < lgd_ctx::EV_RING; ++i)
     for (int j = 0; j < 4; ++j)
       if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
@@ -392,6 +406,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "overlap")) c->p_overlap = value;  // 0: every scan on the caller's stream
   else if (!strcmp(name, "album_slots")) c->p_album_slots = value;  // short-term slots of album record 1
   else if (!strcmp(name, "tp_prune")) c->p_tp_prune = value;  // 0: evaluate every interpolator window
+  else if (!strcmp(name, "group_streams")) { c->p_group_streams = value; return LGD_OK; }  // 0: groups one after the other
   else if (!strcmp(name, "album_world")) c->p_album_world = value ? value : 8;  // ranks the multi-GPU album scratch is sized for
   else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
   c->planned = false;
@@ -402,7 +417,7 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   const size_t lds_cap = 160 * 1024;  // per CU == per workgroup limit on gfx950
   if (forced) {
     for (const int *p = lgd_chunk_table; *p; ++p)
-      if (*p == forced && s100 % *p == 0 && (nch <= 2 || *p == 25 || (*p == 35 && nch != 5)) &&
+      if (*p == forced && s100 % *p == 0 && (nch <= 2 || *p <= 50) &&
           lgd_scan_lds_bytes(*p, (int)nch, tp, nch > 2 && !((nch >= 3 && nch <= 6) || nch == 8)) <= lds_cap)
         return *p;
     return 0;
@@ -414,10 +429,14 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   // short chunks keep its prefetch registers within that
   static const int pref_many[] = {25, 35, 45, 49, 50, 63, 75, 0};
   // 3, 4, 6 (5.1), 8 (7.1) planes per workgroup: the two short chunks compiled for them
-  static const int pref_51[] = {35, 25, 0};
-  static const int pref_5[] = {25, 0};  // 5 planes: C = 35 spills and loses to the run-time-channel kernel
+  // (measured, tools/rate_sweep.py: with six or eight waves per workgroup the short chunk wins -- four
+  // workgroups per CU instead of two -- 43 % vs 38 % of the HBM peak for 5.1 at 48 kHz; three or four
+  // planes fit twice at C = 50: 52 / 56 % vs 41 / 50 %)
+  static const int pref_34[] = {50, 45, 49, 35, 25, 0};
+  static const int pref_51[] = {25, 45, 35, 49, 50, 0};
+  static const int pref_5[] = {25, 35, 0};  // 5 planes: longer chunks spill 25+ registers at 3 waves per SIMD
   const bool multi = (nch >= 3 && nch <= 6) || nch == 8;  // planar specialisations exist
-  const int *pref = nch <= 2 ? pref_fast : (nch == 5 ? pref_5 : (multi ? pref_51 : pref_many));
+  const int *pref = nch <= 2 ? pref_fast : (nch == 5 ? pref_5 : (nch <= 4 ? pref_34 : (multi ? pref_51 : pref_many)));
   const bool generic = nch > 2 && !multi;
   for (int pass = 0; pass < 2; ++pass)
     for (const int *p = pref; *p; ++p)
@@ -633,6 +652,16 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     c->groups[gi].seg_begin = c->segs.size();
     c->groups[gi].seg_count = group_segs[gi].size();
     c->segs.insert(c->segs.end(), group_segs[gi].begin(), group_segs[gi].end());
+  }
+  {  // launch order: most PCM bytes first
+    std::vector<double> bytes(c->groups.size(), 0.0);
+    for (size_t gi = 0; gi < c->groups.size(); ++gi)
+      for (const LgdSeg &sg : group_segs[gi])
+        bytes[gi] += (double)(sg.f_peak_end - sg.f0) * c->groups[gi].nch;
+    c->group_order.resize(c->groups.size());
+    for (size_t gi = 0; gi < c->groups.size(); ++gi) c->group_order[gi] = gi;
+    std::stable_sort(c->group_order.begin(), c->group_order.end(),
+                     [&](size_t a, size_t b) { return bytes[a] > bytes[b]; });
   }
 
   HIPCHK(hipDeviceSynchronize());  // nothing of an older plan may still be running
@@ -860,10 +889,29 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   }
   hipEvent_t *ev = c->ev[c->n_exec % lgd_ctx::EV_RING];
   if (c->p_timing) HIPCHK(hipEventRecord(ev[0], s));
-  for (size_t gi = 0; gi < c->groups.size(); ++gi) {
+  // One scan launch per (rate, channels) group, largest first.  "group_streams" 1 sends the
+  // groups of a mixed plan (C5: twelve) out on up to four streams at once so that a group's
+  // workgroups fill the CUs the previous one leaves idle in its last round -- measured on C5:
+  // 2.88 ms instead of 2.65 ms for the scan kernels (kernels of different LDS footprints share
+  // CUs badly, and every cross-stream dependency costs its latency), hence off by default; every
+  // group is sized to fill the GPU by itself instead (see the segment lengths in lgd_plan).
+  const size_t ng = c->groups.size();
+  const int n_side = (c->p_group_streams && ng > 1) ? (int)std::min<size_t>(ng - 1, lgd_ctx::GSTREAMS) : 0;
+  if (n_side) {
+    HIPCHK(hipEventRecord(c->ev_fork, s));
+    for (int i = 0; i < n_side; ++i) HIPCHK(hipStreamWaitEvent(c->gstream[i], c->ev_fork, 0));
+  }
+  for (size_t k = 0; k < ng; ++k) {
+    const size_t gi = c->group_order[k];
     const Group &g = c->groups[gi];
+    const int lane = n_side ? (int)(k % (size_t)(n_side + 1)) : 0;
+    hipStream_t gs = lane == 0 ? s : c->gstream[lane - 1];
     HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, g.generic ? 1 : 0, w.d_segs + g.seg_begin,
-                           (int)g.seg_count, c->d_filt + gi, s));
+                           (int)g.seg_count, c->d_filt + gi, gs));
+  }
+  for (int i = 0; i < n_side; ++i) {
+    HIPCHK(hipEventRecord(c->ev_gjoin[i], c->gstream[i]));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_gjoin[i], 0));
   }
   if (c->p_timing) HIPCHK(hipEventRecord(ev[3], s));
   // per-channel sample peaks of the whole tracks, then the interpolator over the chunks that

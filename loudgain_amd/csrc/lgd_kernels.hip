@@ -928,7 +928,7 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, 
     return launch_scan_t<C, 1, 0>(segs, n_seg, F, nch, s);
   }
   if (nch > 2) {  // 3 .. 6 or 8 planes per workgroup (2.1, quad, 5.0, 5.1, 7.1): the short chunks only
-    if constexpr (C == 25 || C == 35) {  // (45 / 50 spill 50+ registers with the interpolator)
+    if constexpr (C <= 50) {
 #define LGD_DISPATCH_G(g_)                                                              \
       if (nch == g_) {                                                                  \
         if (tp == 4) return launch_scan_t<C, g_, 4>(segs, n_seg, F, nch, s);            \

@@ -491,3 +491,37 @@ def test_long_track_range_selection(scanner, oracle):
     check_track(got, ref, rate=rate)
     assert abs(got["lra"] - ref["lra"]) <= 1e-9
     assert abs(album["lra"] - ref["lra"]) <= 1e-9 and album["n_st"] == ref["n_st"]
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_pcm_buffer_reuse_between_executes(oracle, overlap):
+    """A caller that refills ONE device buffer between scans (the ingest loop that replaces
+    scan.c:225-250).  Default ("overlap" 0): every scan runs on the caller's stream, so a copy
+    enqueued on that stream behind lgd_execute is ordered behind the scan like behind any kernel.
+    "overlap" 1: scans may run on the engine's own stream; the writer must be ordered behind them
+    with lgd_join first."""
+    import torch
+    from loudgain_amd.device import DeviceScanner
+    rate = 48000
+    n = rate * 240
+    src = [synth.track_numpy(n, 2, rate, seed=300 + i, step_s=3.0 + i) for i in range(4)]
+    refs = [oracle.scan_track(p, rate) for p in src]
+    host = [torch.from_numpy(p).pin_memory() for p in src]
+    sc = DeviceScanner(0)
+    sc.set_param("overlap", overlap)
+    stream = torch.cuda.Stream()
+    buf = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    sc.plan([buf], rate, true_peak=True)
+    got = []
+    with torch.cuda.stream(stream):
+        for i in range(4):
+            if overlap:
+                sc.join(stream)                      # the scans of the previous rounds have read `buf`
+            buf.copy_(host[i], non_blocking=True)    # refill, no host synchronisation
+            sc.execute(stream)
+            if i % 2 == 1:                           # results are read only every other round
+                (r,), _ = sc.fetch()
+                got.append((i, r))
+    for i, r in got:
+        check_track(r, refs[i])
+    sc.close()

@@ -1,26 +1,54 @@
-"""Kernel time per sample at the common sample rates / layouts (serial launches, hipEvents)."""
-import os, sys
+"""Kernel time at the common sample rates / layouts: the same number of samples as C2 (345.6 M) per
+case, serial launches, hipEvents on the launch stream (scan kernels alone, and with the true-peak
+kernels behind them).  Output is committed as profiles/rNN_rate_sweep.txt.
+  python tools/rate_sweep.py [--chunk C] [--only 5.1]"""
+import argparse
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from loudgain_amd import synth
 from loudgain_amd.device import DeviceScanner
-for rate, ch, tp in [(48000, 2, False), (44100, 2, False), (44100, 2, True), (48000, 2, True), (96000, 2, False), (96000, 2, True),
-                     (192000, 2, True), (22050, 2, False), (32000, 2, False), (48000, 1, False), (44100, 1, True), (48000, 6, True)]:
-    frames = int(172800000 * 2 / ch)          # same number of samples as C2
-    frames -= frames % (rate // 10) if False else 0
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--chunk", type=int, default=0)
+ap.add_argument("--only", default="")
+a = ap.parse_args()
+CASES = [(48000, 2), (44100, 2), (96000, 2), (192000, 2), (22050, 2), (32000, 2), (48000, 1), (44100, 1),
+         (48000, 3), (48000, 4), (48000, 5), (44100, 5), (48000, 6), (44100, 6), (96000, 6), (192000, 6),
+         (48000, 7), (48000, 8), (48000, 12), (48000, 24)]
+if a.only == "5.1":
+    CASES = [c for c in CASES if c[1] == 6]
+elif a.only == "multi":
+    CASES = [c for c in CASES if c[1] > 2]
+print("%-7s %-3s %-5s %-6s | %-28s | %-28s" % ("rate", "ch", "chunk", "segs", "no true peak: ms, % of 8 TB/s",
+                                               "true peak: scan ms, scan+tp ms, %"))
+for rate, ch in CASES:
+    frames = int(172800000 * 2 / ch)
     pcm = synth.track_torch(frames, ch, rate, seed=1, device="cuda")
-    sc = DeviceScanner(0)
-    sc.set_param("overlap", 0)
-    sc.plan([pcm], rate, true_peak=tp)
-    s = torch.cuda.Stream()
-    for _ in range(3): sc.execute(s)
-    sc.fetch()
-    for _ in range(30): sc.execute(s)
-    sc.fetch()
-    ks = sc.kernel_ms_stats(30)
-    info = sc.plan_info()
     nbytes = frames * ch * 4
-    print("rate %6d ch %d tp %d: chunk %2d segs %5d kernel %.4f ms  %.1f GB/s (%.1f %% of 8 TB/s)  %.0f Msamples/s" % (
-        rate, ch, tp, info["chunk"], info["segments"], ks["scan_mean_ms"], nbytes / ks["scan_mean_ms"] / 1e6,
-        nbytes / ks["scan_mean_ms"] / 1e6 / 80.0, frames * ch / ks["scan_mean_ms"] / 1e3), flush=True)
-    sc.close(); del pcm; torch.cuda.empty_cache()
+    row = []
+    for tp in (False, True):
+        sc = DeviceScanner(0)
+        sc.set_param("overlap", 0)
+        if a.chunk:
+            sc.set_param("chunk", a.chunk)
+        sc.plan([pcm], rate, true_peak=tp)
+        s = torch.cuda.Stream()
+        for _ in range(20):
+            sc.execute(s)
+        sc.fetch()
+        for _ in range(30):
+            sc.execute(s)
+        sc.fetch()
+        ks = sc.kernel_ms_stats(30)
+        info = sc.plan_info()
+        row.append((ks, info))
+        sc.close()
+    (k0, info), (k1, _) = row
+    print("%-7d %-3d %-5d %-6d | %7.4f ms  %5.1f %%           | %7.4f  %7.4f ms  %5.1f %%" % (
+        rate, ch, info["chunk"], info["segments"], k0["scan_mean_ms"], nbytes / k0["scan_mean_ms"] / 1e6 / 80.0,
+        k1["scan_only_mean_ms"], k1["scan_mean_ms"], nbytes / k1["scan_mean_ms"] / 1e6 / 80.0), flush=True)
+    del pcm
+    torch.cuda.empty_cache()
