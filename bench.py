@@ -67,6 +67,8 @@ def parse_args(argv=None):
                     help="rehearsal of the N>1 path on one GPU: RCCL group of one rank, album exchange every step")
     ap.add_argument("--serial", action="store_true",
                     help="no stream pipelining of consecutive scans (the mode rocprofv3 kernel durations are quoted in)")
+    ap.add_argument("--settle", type=int, default=-1, help="serial launches before the kernel timing (-1 = default)")
+    ap.add_argument("--launches", type=int, default=-1, help="serial launches timed for the roofline (-1 = default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the launcher")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: ranks rendezvous, all-reduce one number, rank 0 prints a JSON line")
@@ -444,8 +446,8 @@ def main():
     warmup = args.warmup if args.warmup >= 0 else {"c2": 20, "c3": 20, "c4": 3, "c5": 5}[workload]
 
     overlapped = not args.serial
-    settle = {"c2": 300, "c3": 300, "c4": 3, "c5": 20}[workload]
-    launches = {"c2": 64, "c3": 64, "c4": 8, "c5": 32}[workload]
+    settle = args.settle if args.settle >= 0 else {"c2": 300, "c3": 300, "c4": 3, "c5": 20}[workload]
+    launches = args.launches if args.launches > 0 else {"c2": 64, "c3": 64, "c4": 8, "c5": 32}[workload]
     ks = run.kernel_stats(tracks, rates, true_peak, album and not distributed, launches, settle)
     sc.set_param("overlap", 1 if overlapped else 0)
     if distributed:

@@ -718,15 +718,6 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
   const gflt_ptr pcm = (gflt_ptr)sg.pcm + chan;
   const int CH = C + HX, NSTEP = C / U;
 
-  float tpa[12 + 1], tpb[6 + 1];
-  f32x2 tpsd[6 + 1];  // 4x: halved (sum, difference) coefficients of the mirrored phase pair
-#pragma unroll
-  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpsd[i] = (f32x2){F0->tp[18 + 2 * i], F0->tp[19 + 2 * i]};
-#pragma unroll
-  for (int i = 0; i < (TP == 2 ? 12 : 0); ++i) tpa[i] = F0->tp[i];
-#pragma unroll
-  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpb[i] = F0->tp[12 + i];
-  (void)tpa; (void)tpb; (void)tpsd;
 
   // Exact pruning: an interpolated output is sum_k c_k x[n-k], so it cannot exceed L1 * (largest
   // |x| it reads), L1 = largest sum |c_k| of a phase.  sg.hint holds this channel's sample peak
@@ -769,6 +760,15 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
   }
   const int n_chunks = __popcll(mask);
   if (n_chunks == 0) return;
+  float tpa[12 + 1], tpb[6 + 1];
+  f32x2 tpsd[6 + 1];  // 4x: halved (sum, difference) coefficients of the mirrored phase pair
+#pragma unroll
+  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpsd[i] = (f32x2){F0->tp[18 + 2 * i], F0->tp[19 + 2 * i]};
+#pragma unroll
+  for (int i = 0; i < (TP == 2 ? 12 : 0); ++i) tpa[i] = F0->tp[i];
+#pragma unroll
+  for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpb[i] = F0->tp[12 + i];
+  (void)tpa; (void)tpb; (void)tpsd;
   // entry o of the table: the o-th set bit of the mask
   if ((mask >> lane) & 1ull)
     chunk_of[wave][__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;

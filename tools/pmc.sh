@@ -17,6 +17,6 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-c3 --no-h2d --settle 2 --launches 4 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 $REPO/tools/pmc_parse.py $OUT | tee $OUT/summary.txt

@@ -6,7 +6,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            short = "scan" if "lgd_scan_kernel" in k else ("epi:" + k.split("(")[0][:24] if k.startswith("lgd_") else None)
+            short = ("scan" if "lgd_scan_kernel" in k else "tp" if "lgd_tp_kernel" in k
+                     else ("epi:" + k.split("(")[0][:24] if k.startswith("lgd_") else None))
             if short is None:
                 continue
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))

@@ -1,17 +1,22 @@
 #!/bin/bash
-# Collects the evidence committed under profiles/: default bench line, rocprofv3
-# kernel-trace stats of the same command, PMC passes (counters only).
+# Collects the evidence committed under profiles/ (see profiles/README.md): bench lines, rocprofv3
+# kernel-trace stats of the same commands (serial launches: the mode kernel durations are quoted in),
+# PMC passes (counters only), the rate / layout sweep.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 mkdir -p gpurun_out
-timeout -k 10 600 python bench.py > gpurun_out/${TAG}_bench_c2.json 2> gpurun_out/${TAG}_bench_c2.err; echo "bench c2 rc=$?"
-timeout -k 10 600 python bench.py --workload c3 --no-cpu-baseline > gpurun_out/${TAG}_bench_c3.json 2> gpurun_out/${TAG}_bench_c3.err; echo "bench c3 rc=$?"
-# kernel durations: --serial (no overlap of consecutive scans) is the mode the roofline
-# figure is quoted in; the default (pipelined) command is traced too
-bash tools/prof1.sh ${TAG}_c2 --serial > gpurun_out/${TAG}_prof_c2.log 2>&1
-bash tools/prof1.sh ${TAG}_c2_pipelined > gpurun_out/${TAG}_prof_c2_pipelined.log 2>&1
-bash tools/prof1.sh ${TAG}_c3 --workload c3 --serial > gpurun_out/${TAG}_prof_c3.log 2>&1
-bash tools/pmc.sh ${TAG}_c2 --serial > gpurun_out/${TAG}_pmc_c2.log 2>&1
-cut -c1-600 gpurun_out/${TAG}_bench_c2.json; echo; cut -c1-300 gpurun_out/${TAG}_bench_c3.json; echo
-head -4 gpurun_out/prof_${TAG}_c2/kernel_stats.csv | cut -c1-200
-grep -A28 "== scan" gpurun_out/pmc_${TAG}_c2/summary.txt | head -30
+timeout -k 10 600 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench default rc=$?"
+for w in c3 c4 c5; do
+  timeout -k 10 600 python bench.py --workload $w --no-cpu-baseline > gpurun_out/${TAG}_bench_$w.json 2> gpurun_out/${TAG}_bench_$w.err; echo "bench $w rc=$?"
+done
+for w in c2 c3 c5; do
+  bash tools/prof1.sh ${TAG}_$w --workload $w --serial > gpurun_out/${TAG}_prof_$w.log 2>&1
+done
+bash tools/prof1.sh ${TAG}_c3_adversarial --workload c3 --serial --material adversarial --steps 300 > gpurun_out/${TAG}_prof_c3_adv.log 2>&1
+bash tools/prof1.sh ${TAG}_c4 --workload c4 --serial --steps 12 --warmup 2 > gpurun_out/${TAG}_prof_c4.log 2>&1
+bash tools/prof1.sh ${TAG}_c2_pipelined --workload c2 > gpurun_out/${TAG}_prof_c2_pipelined.log 2>&1
+bash tools/pmc.sh ${TAG}_c2 --workload c2 --serial > gpurun_out/${TAG}_pmc_c2.log 2>&1
+bash tools/pmc.sh ${TAG}_c3 --workload c3 --serial > gpurun_out/${TAG}_pmc_c3.log 2>&1
+timeout -k 10 900 python tools/rate_sweep.py > gpurun_out/${TAG}_rate_sweep.txt 2>/dev/null
+for f in default c3 c4 c5; do cut -c1-400 gpurun_out/${TAG}_bench_$f.json; echo; done
+for w in c2 c3 c4 c5; do head -5 gpurun_out/prof_${TAG}_$w/kernel_stats.csv | cut -c1-160; done
