@@ -505,7 +505,7 @@ def main():
     # one GPU, c2: the reference's own semantics (true peak on) beside it, standard and adversarial material
     if rank == 0 and world == 1 and workload == "c2" and not args.no_c3 and not distributed:
         from loudgain_amd import synth
-        c3steps = max(10, steps // 2)
+        c3steps = steps
         ks3 = run.kernel_stats(tracks, rates, True, False, 64, 300)
         sc.set_param("overlap", 1 if overlapped else 0)
         job3 = sc.plan(tracks, rates, true_peak=True, album=False)
