@@ -222,6 +222,7 @@ struct Group {  // tracks sharing (rate, channels) -> one scan launch
   unsigned rate, nch, nch_total;  // nch: channels (waves) per workgroup
   int chunk, tp;
   bool generic;
+  bool strided;  // channel pairs of a wider interleaved stream (lgd_scan_kernel<.., STR>)
   LgdFilt F;
   size_t seg_begin, seg_count;
   int rows_max;  // most true-peak candidate rows (tiles x channels) of any of its segments
@@ -232,7 +233,7 @@ static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at m
 struct lgd_ctx {
   int device = 0;
   long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 0,
-       p_album_slots = 0, p_tp_prune = 1, p_album_world = 8, p_group_streams = 0;
+       p_album_slots = 0, p_tp_prune = 1, p_album_world = 8, p_group_streams = 0, p_strided = 1;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -407,6 +408,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "album_slots")) c->p_album_slots = value;  // short-term slots of album record 1
   else if (!strcmp(name, "tp_prune")) c->p_tp_prune = value;  // 0: evaluate every interpolator window
   else if (!strcmp(name, "group_streams")) { c->p_group_streams = value; return LGD_OK; }  // 0: groups one after the other
+  else if (!strcmp(name, "strided")) c->p_strided = value;  // channel-pair workgroups: 0 never, 1 where measured faster, 2 every 3+ channel layout
   else if (!strcmp(name, "album_world")) c->p_album_world = value ? value : 8;  // ranks the multi-GPU album scratch is sized for
   else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
   c->planned = false;
@@ -551,9 +553,27 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   const uint64_t max_seg = 48;
   struct RC { unsigned rate, ch; bool operator<(const RC &o) const { return rate != o.rate ? rate < o.rate : ch < o.ch; } };
   std::map<RC, uint64_t> key_sb, key_seg;
-  for (uint32_t t = 0; t < n; ++t) key_sb[RC{tracks[t].rate, tracks[t].channels}] += (uint64_t)c->meta[t].n_sb;
+  // Streams as stereo-shaped workgroups, one per channel pair (the last pair of an odd count
+  // overlaps its neighbour): possible whenever a stereo chunk length divides the sub-block.  Every
+  // pair's workgroup pulls all of the stream's cache lines through L1 (L2 / Infinity Cache serve the
+  // siblings), so it only pays where the many-plane kernels are weak -- measured (345.6 M samples,
+  // tools/rate_sweep.py, "strided" 2 = every layout): 5 channels 40 % of the HBM peak instead of
+  // 27 %, 7 channels 34 vs 30 %, 24 channels 12 vs 10 %; but 3 / 4 / 5.1 / 7.1 / 12 channels 38 / 52 /
+  // 44 / 29 / 19 % against 54 / 56 / 45 / 41 / 42 % on the planar kernels.
+  auto strided_for = [&](unsigned rate, unsigned ch) -> bool {
+    if (!c->p_strided || ch < 3) return false;
+    if (c->p_strided == 1 && !(ch == 5 || ch == 7 || ch > LGD_GROUP_CH)) return false;
+    const int tp_ = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(rate) : 0;
+    return pick_chunk(c->p_chunk, (int)((rate + 5) / 10), 2, tp_) != 0;
+  };
+  for (uint32_t t = 0; t < n; ++t) {
+    const unsigned ch = tracks[t].channels;
+    const uint64_t mult = strided_for(tracks[t].rate, ch) ? (ch + 1) / 2 : 1;  // one segment set per pair
+    key_sb[RC{tracks[t].rate, ch}] += (uint64_t)c->meta[t].n_sb * mult;
+  }
   for (const auto &kv : key_sb) {
-    const unsigned k = std::min<unsigned>(kv.first.ch, LGD_GROUP_CH);
+    const bool str = strided_for(kv.first.rate, kv.first.ch);
+    const unsigned k = str ? 2u : std::min<unsigned>(kv.first.ch, LGD_GROUP_CH);
     const unsigned per_cu = k <= 2 ? std::max(1u, (unsigned)c->p_waves_per_cu / k)
                                    : (k > 8 ? std::max(1u, 16u / k) : std::max(1u, 12u / k));
     const uint64_t slots = (uint64_t)c->n_cu * per_cu;
@@ -574,8 +594,19 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     m.n_seg = (int)nseg;
     m.peak_off = (long long)c->total_peak_floats;
     c->total_peak_floats += nseg * 2ull * tr.channels;
-    for (unsigned ch0 = 0; ch0 < tr.channels; ch0 += LGD_GROUP_CH) {
-      const unsigned g_nch = std::min<unsigned>(LGD_GROUP_CH, tr.channels - ch0);
+    const bool strided = strided_for(tr.rate, tr.channels);
+    std::vector<unsigned> ch0s;  // first channel of every workgroup set of this track
+    if (strided) {
+      for (unsigned a = 0; a + 1 < tr.channels; a += 2) ch0s.push_back(a);
+      if (tr.channels & 1) ch0s.push_back(tr.channels - 2);  // (channel nch-2 twice: same results, one launch)
+    } else {
+      for (unsigned a = 0; a < tr.channels; a += LGD_GROUP_CH) ch0s.push_back(a);
+    }
+    std::vector<std::vector<LgdSeg>> pair_segs(ch0s.size());
+    size_t pair_group = 0;
+    for (size_t pi = 0; pi < ch0s.size(); ++pi) {
+      const unsigned ch0 = ch0s[pi];
+      const unsigned g_nch = strided ? 2u : std::min<unsigned>(LGD_GROUP_CH, tr.channels - ch0);
       const Key key{tr.rate, tr.channels, g_nch};
       auto it = group_of.find(key);
       if (it == group_of.end()) {
@@ -584,8 +615,10 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         g.nch = g_nch;
         g.nch_total = tr.channels;
         g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
-        g.chunk = ((g_nch <= 6 || g_nch == 8) && g_nch == tr.channels)
-                      ? pick_chunk(c->p_chunk, s100, g_nch, g.tp) : 0;
+        g.strided = strided;
+        g.chunk = strided ? pick_chunk(c->p_chunk, s100, 2, g.tp)
+                          : (((g_nch <= 6 || g_nch == 8) && g_nch == tr.channels)
+                                 ? pick_chunk(c->p_chunk, s100, g_nch, g.tp) : 0);
         // fast kernels: mono / stereo with a chunk that divides the sub-block; anything else
         // (more channels, channel groups, rates such as 11 025 Hz) goes to the generic kernel,
         // where sub-block boundaries may fall inside a chunk
@@ -645,10 +678,23 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
           g.rows_max = std::max(g.rows_max, (int)rows);
         }
         sg.peak_out = (float *)(uintptr_t)(m.peak_off + (long long)(sgi * 2ull * tr.channels));
-        group_segs[it->second].push_back(sg);
+        pair_segs[pi].push_back(sg);
         if (sb0) c->warm_bytes += (uint64_t)warm_tiles * tile_f * g_nch * 4ull;
         sb0 += cnt;
       }
+      pair_group = it->second;
+      if (!strided) {
+        group_segs[it->second].insert(group_segs[it->second].end(), pair_segs[pi].begin(), pair_segs[pi].end());
+        pair_segs[pi].clear();
+      }
+    }
+    if (strided) {
+      // the workgroups of one segment's channel pairs read the same cache lines: emit them 8 apart
+      // (workgroups b and b + 8 are dispatched to the same XCD, i.e. the same L2), 8 segments at a time
+      std::vector<LgdSeg> &out = group_segs[pair_group];
+      for (uint64_t base = 0; base < nseg; base += 8)
+        for (size_t pi = 0; pi < ch0s.size(); ++pi)
+          for (uint64_t sgi = base; sgi < std::min<uint64_t>(nseg, base + 8); ++sgi) out.push_back(pair_segs[pi][sgi]);
     }
   }
   for (size_t gi = 0; gi < c->groups.size(); ++gi) {
@@ -909,7 +955,7 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
     const Group &g = c->groups[gi];
     const int lane = n_side ? (int)(k % (size_t)(n_side + 1)) : 0;
     hipStream_t gs = lane == 0 ? s : c->gstream[lane - 1];
-    HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, g.generic ? 1 : 0, w.d_segs + g.seg_begin,
+    HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, g.strided ? 2 : (g.generic ? 1 : 0), w.d_segs + g.seg_begin,
                            (int)g.seg_count, c->d_filt + gi, gs));
   }
   for (int i = 0; i < n_side; ++i) {

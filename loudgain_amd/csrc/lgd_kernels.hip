@@ -179,7 +179,12 @@ struct ScanCfg {
 // short chunks)
 // WIDE (run-time-G kernel only): up to 16 waves per workgroup -> <= 128 VGPRs;
 // otherwise up to 8 waves (<= 256 VGPRs, no spills).
-template <int C, int G, int TP, bool WIDE = false>
+// STR (G = 1 or 2 only): the workgroup takes channels [sg.ch0, sg.ch0 + G) of a stream of sg.nch_total
+// interleaved channels -- one frame per lane and load (a dword or an aligned pair), sibling
+// workgroups of the other channel pairs read the same lines through L2 / Infinity Cache.  Every
+// layout then runs the mono / stereo kernel's long chunks (a six-plane tile of C = 75 would not
+// fit LDS twice).
+template <int C, int G, int TP, bool WIDE = false, bool STR = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
                                                       G ? LGD_WAVE * G : (WIDE ? 1024 : 512)),
                           amdgpu_waves_per_eu(G ? (G > 2 ? 3 : 2) : (WIDE ? 4 : 2), 4))) void lgd_scan_kernel(
@@ -200,7 +205,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   const int ch = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = LGD_WAVE * nch;
   const LgdSeg sg = segs[blockIdx.x];
-  const int shift = (G == 0 && sg.nch_total != (G ? G : nch_rt)) ? 0 : (int)((sg.f0 * nch) & 3);
+  static_assert(!STR || G == 1 || G == 2, "strided variant: one or two channels per workgroup");
+  const int shift = (STR || (G == 0 && sg.nch_total != (G ? G : nch_rt))) ? 0 : (int)((sg.f0 * nch) & 3);
   const long long n_frames = sg.n_frames;
   const int nvec = ((K::TILE_F + K::HALO) * nch + 4) >> 2;  // 16-B vectors per tile
   // frame slot of tile frame -HALO inside a plane
@@ -214,8 +220,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   constexpr int PLANE = (K::HALO + 4 + LL::PAD + LGD_WAVE * LL::STRIDE + 4 + 8 + 1) & ~1;
   // channel groups (streams with more than 16 channels, run-time-G kernel only):
   // this workgroup handles channels [ch0, ch0 + nch) of an nch_tot-channel stream
-  const int ch0 = G ? 0 : sg.ch0;
-  const int nch_tot = G ? G : sg.nch_total;
+  const int ch0 = (G && !STR) ? 0 : sg.ch0;
+  const int nch_tot = (G && !STR) ? G : sg.nch_total;
   const bool grouped = (G == 0) && (nch_tot != nch);
   const bool filt = lgd_channel_weight(ch0 + ch, nch_tot) > 0.0;  // wave-uniform
 
@@ -273,7 +279,38 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       }                                                                                 \
     }                                                                                   \
   } while (0)
-  if (-sg.n_warm_tiles < n_main) LGD_PREFETCH(-sg.n_warm_tiles);
+  // ---- strided variant: one frame of this workgroup's channels per lane and load
+  constexpr int NFR = K::TILE_F + K::HALO;                              // frames staged per tile
+  constexpr int NVS = STR ? (NFR + LGD_WAVE * (G ? G : 1) - 1) / (LGD_WAVE * (G ? G : 1)) : 1;
+  typedef const f32x2 LGD_GLOBAL *gvec2_ptr;
+  f32x2 pfs[NVS];
+#pragma unroll
+  for (int i = 0; i < NVS; ++i) pfs[i] = (f32x2){0.f, 0.f};
+  // (an aligned pair of channels is one 8-B load; odd channel counts take two dwords)
+  const bool aligned2 = STR && G == 2 && !((nch_tot | ch0) & 1);
+#define LGD_PREFETCH_STR(kk)                                                            \
+  do {                                                                                  \
+    const long long fb_ = sg.f0 + (long long)(kk) * K::TILE_F - K::HALO;                \
+    pf_valid = (fb_ >= 0) && (fb_ + NFR <= n_frames); /* uniform */                     \
+    if (dbg & 1) pf_valid = false;                                                      \
+    if (pf_valid) {                                                                     \
+      const gflt_ptr src_ = (gflt_ptr)sg.pcm + fb_ * nch_tot + ch0;                     \
+      const unsigned lo_ = (unsigned)(tid * nch_tot);                                   \
+      _Pragma("unroll") for (int i_ = 0; i_ < NVS; ++i_) {                              \
+        gflt_ptr src_i_ = src_ + (long long)(nthreads * i_) * nch_tot;                  \
+        asm volatile("" : "+s"(src_i_));                                                \
+        if (nthreads * (i_ + 1) <= NFR || tid + nthreads * i_ < NFR) {                  \
+          if (G == 2 && aligned2) pfs[i_] = *(gvec2_ptr)(src_i_ + lo_);                 \
+          else {                                                                        \
+            pfs[i_].x = src_i_[lo_];                                                    \
+            if (G == 2) pfs[i_].y = src_i_[lo_ + 1u];                                   \
+          }                                                                             \
+        }                                                                               \
+      }                                                                                 \
+    }                                                                                   \
+  } while (0)
+#define LGD_PREFETCH_ANY(kk) do { if constexpr (STR) LGD_PREFETCH_STR(kk); else LGD_PREFETCH(kk); } while (0)
+  if (-sg.n_warm_tiles < n_main) LGD_PREFETCH_ANY(-sg.n_warm_tiles);
 
   for (int k = -sg.n_warm_tiles; k < n_main; ++k) {
     const long long tb = sg.f0 + (long long)k * K::TILE_F;  // first frame of the tile
@@ -304,7 +341,32 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         }                                                                                \
       }                                                                                  \
     } while (0)
-    if (pf_valid && !(dbg & 64)) {
+    if constexpr (STR) {
+      // frame fr (0 = tile frame -HALO) of plane c sits at fr + PAD * floor((fr - HALO + C) / C)
+#define LGD_STORE_FRAME(fr_, a_, b_)                                                    \
+      do {                                                                              \
+        const int at_ = (fr_) + LL::PAD * (int)((unsigned)((fr_) - K::HALO + C) / (unsigned)C); \
+        lds[at_] = (a_);                                                                \
+        if (G == 2) lds[PLANE + at_] = (b_);                                            \
+      } while (0)
+      if (pf_valid && !(dbg & 64)) {
+#pragma unroll
+        for (int i = 0; i < NVS; ++i) {
+          const int fr = tid + nthreads * i;
+          if (nthreads * (i + 1) <= NFR || fr < NFR) LGD_STORE_FRAME(fr, pfs[i].x, pfs[i].y);
+        }
+      } else if (!(dbg & 1) && !(dbg & 64)) {  // a tile at a track edge: frames outside the track are zero
+        const gflt_ptr gp = (gflt_ptr)sg.pcm + ch0;
+        for (int fr = tid; fr < NFR; fr += nthreads) {
+          const long long f = tb - K::HALO + fr;
+          const bool in = f >= 0 && f < n_frames;
+          const float a = in ? gp[f * nch_tot] : 0.f;
+          const float b = (in && G == 2) ? gp[f * nch_tot + 1] : 0.f;
+          LGD_STORE_FRAME(fr, a, b);
+        }
+      }
+#undef LGD_STORE_FRAME
+    } else if (pf_valid && !(dbg & 64)) {
 #pragma unroll
       for (int i = 0; i < K::NV; ++i) {
         const int idx = tid + nthreads * i;
@@ -340,7 +402,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     }
 #undef LGD_STORE_VEC
     __syncthreads();
-    if (k + 1 < n_main) LGD_PREFETCH(k + 1); else pf_valid = false;
+    if (k + 1 < n_main) LGD_PREFETCH_ANY(k + 1); else pf_valid = false;
     // the chunk maxima of the last LGD_ROW_TILES tiles go out here
     if constexpr (TP != 0) {
       // (behind the loads just issued, and only one store per LGD_ROW_TILES tiles: a vector store
@@ -590,7 +652,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           if (k * LGD_WAVE + LGD_WAVE >= cur_q + lps) {  // `cur` ends in this tile
             const double tot = wave_sum_f64(acc) * pb0sq;
             if (lane == 0 && cur < sg.n_sb)
-              ((double LGD_GLOBAL *)sg.e_out)[(long long)ch * sg.e_ch_stride + cur] = tot;
+              ((double LGD_GLOBAL *)sg.e_out)[(long long)(ch0 + ch) * sg.e_ch_stride + cur] = tot;
             acc = 0.0;
             ++cur;
             cur_q += lps;
@@ -895,18 +957,31 @@ extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
   return ((size_t)(LGD_WAVE * chunk + halo + 8) * nch + 4) * sizeof(float) + queue;
 }
 
-template <int C, int G, int TP, bool WIDE = false>
+template <int C, int G, int TP, bool WIDE = false, bool STR = false>
 static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, const LgdFilt *F, int nch,
                                 hipStream_t s) {
   const size_t lds_bytes = lgd_scan_lds_bytes(C, nch, TP, G == 0);
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)lgd_scan_kernel<C, G, TP, WIDE>,
+    hipError_t e = hipFuncSetAttribute((const void *)lgd_scan_kernel<C, G, TP, WIDE, STR>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((lgd_scan_kernel<C, G, TP, WIDE>), dim3(n_seg), dim3(LGD_WAVE * nch), lds_bytes, s,
+  hipLaunchKernelGGL((lgd_scan_kernel<C, G, TP, WIDE, STR>), dim3(n_seg), dim3(LGD_WAVE * nch), lds_bytes, s,
                      segs, F, nch);
   return hipGetLastError();
+}
+
+// channel pairs (or single channels) of a wider interleaved stream
+template <int C>
+static hipError_t launch_scan_strided(int nch, int tp, const LgdSeg *segs, int n_seg, const LgdFilt *F,
+                                      hipStream_t s) {
+  if (nch == 1) {
+    if (tp) return launch_scan_t<C, 1, 4, false, true>(segs, n_seg, F, nch, s);
+    return launch_scan_t<C, 1, 0, false, true>(segs, n_seg, F, nch, s);
+  }
+  if (nch != 2) return hipErrorInvalidValue;
+  if (tp) return launch_scan_t<C, 2, 4, false, true>(segs, n_seg, F, nch, s);
+  return launch_scan_t<C, 2, 0, false, true>(segs, n_seg, F, nch, s);
 }
 
 // the generic kernel (any channel count, channel groups, any sub-block alignment)
@@ -978,9 +1053,23 @@ extern "C" const int lgd_chunk_table[] = {25, 35, 45, 49, 50, 63, 75, 0};
 
 
 // F: DEVICE pointer to the group's constants
+// generic: 0 = planar kernel of `nch` channels, 1 = run-time-channel kernel, 2 = channel pair /
+// single channel (nch = 2 / 1) of a wider interleaved stream
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, const LgdSeg *segs,
                                       int n_seg, const LgdFilt *F, hipStream_t s) {
   if (n_seg <= 0) return hipSuccess;
+  if (generic == 2) {
+    switch (chunk) {
+      case 25: return launch_scan_strided<25>(nch, tp, segs, n_seg, F, s);
+      case 35: return launch_scan_strided<35>(nch, tp, segs, n_seg, F, s);
+      case 45: return launch_scan_strided<45>(nch, tp, segs, n_seg, F, s);
+      case 49: return launch_scan_strided<49>(nch, tp, segs, n_seg, F, s);
+      case 50: return launch_scan_strided<50>(nch, tp, segs, n_seg, F, s);
+      case 63: return launch_scan_strided<63>(nch, tp, segs, n_seg, F, s);
+      case 75: return launch_scan_strided<75>(nch, tp, segs, n_seg, F, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
   if (nch < 1 || nch > 16) return hipErrorInvalidValue;
   if (generic) {
     if (chunk != LGD_GENERIC_CHUNK) return hipErrorInvalidValue;
