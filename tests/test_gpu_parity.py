@@ -525,3 +525,30 @@ def test_pcm_buffer_reuse_between_executes(oracle, overlap):
     for i, r in got:
         check_track(r, refs[i])
     sc.close()
+
+
+@pytest.mark.parametrize("rate,nch", [(48000, 3), (48000, 4), (44100, 6), (48000, 6), (96000, 8), (48000, 12)])
+def test_channel_pair_workgroups_on_any_layout(oracle, rate, nch):
+    """"strided" 2: every 3+ channel stream as stereo-shaped workgroups, one per channel pair of the
+    interleaved stream (the default uses them for 5 / 7 / 17+ channels only, where they are faster).
+    Same results as the many-plane kernels: both against the oracle, block energies against each other."""
+    from loudgain_amd.device import DeviceScanner
+    frames = int(rate * 7.3) + 11
+    pcm = synth.track_numpy(frames, nch, rate, seed=500 + nch, step_s=1.3)
+    gains = np.array([1.0, 0.7, 0.5, 1.3, 0.9, 0.6, 1.1, 0.8] * 2)[:nch].astype(np.float32)
+    pcm = synth.snap_s16_numpy(pcm * gains[None, :])
+    ref = oracle.scan_track(pcm, rate)
+    out = []
+    for mode in (2, 0):
+        sc = DeviceScanner(0)
+        sc.set_param("strided", mode)
+        (got,), _ = sc.scan([to_dev(pcm)], rate)
+        check_track(got, ref, rate=rate)
+        sp, tp = sc.channel_peaks(0, nch)
+        np.testing.assert_allclose(tp, np.asarray(ref["true_peak"]), atol=1e-4, rtol=0)
+        out.append((got, sc.subblock_energies(0), sp, tp))
+        sc.close()
+    (a, ea, spa, tpa), (b, eb, spb, tpb) = out
+    np.testing.assert_allclose(ea, eb, rtol=energy_rtol(rate))   # (other chunk length: other rounding)
+    assert np.array_equal(spa, spb) and np.array_equal(tpa, tpb)
+    assert (a["n_abs"], a["n_rel"], a["n_st"]) == (b["n_abs"], b["n_rel"], b["n_st"])
