@@ -69,7 +69,10 @@ def parse_args(argv=None):
                     help="no stream pipelining of consecutive scans (the mode rocprofv3 kernel durations are quoted in)")
     ap.add_argument("--settle", type=int, default=-1, help="serial launches before the kernel timing (-1 = default)")
     ap.add_argument("--launches", type=int, default=-1, help="serial launches timed for the roofline (-1 = default)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the launcher")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsals (the launcher on the CPU; with --same-gpu the whole N > 1 path on one GPU)")
+    ap.add_argument("--same-gpu", action="store_true",
+                    help="every rank uses GPU 0 (needs --backend gloo: RCCL wants one device per rank)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: ranks rendezvous, all-reduce one number, rank 0 prints a JSON line")
     return ap.parse_args(argv)
@@ -297,7 +300,7 @@ class Runner:
         barrier()
         dt = time.perf_counter() - t0
         if distributed:
-            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, results
@@ -422,11 +425,17 @@ def main():
     import torch.distributed as dist
     from loudgain_amd.album import DistributedAlbumScanner
 
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_dist
     if distributed:
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the few reduced scalars live
 
     run = Runner(args, rank, world, local_rank)
     sc = run.sc
@@ -437,7 +446,7 @@ def main():
     my_samples = sum(int(t.numel()) for t in tracks)
     algo_bytes = my_samples * 4           # 4 B read per sample, writes ~ 0
     if distributed:
-        t = torch.tensor([my_samples], dtype=torch.int64, device=dev)
+        t = torch.tensor([my_samples], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t)
         total_samples = int(t.item())
     else:
@@ -463,7 +472,8 @@ def main():
     collective = None
     if distributed:
         r1n = job.shard.rec1.numel()
-        collective = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)",
+        collective = {"backend": dist.get_backend(),
+                      "library": "RCCL (torch.distributed 'nccl' on ROCm)" if dist.get_backend() == "nccl" else "gloo (rehearsal)",
                       "world_size": dist.get_world_size(),
                       "per_step": "all_gather of album record 1 (%d doubles per rank) + all_gather of record 2 "
                                   "(2 doubles per rank), on a side stream behind the scan" % r1n,

@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -80,3 +82,20 @@ def test_one_rank_rccl_rehearsal():
     c = d["collective"]
     assert c["backend"] == "nccl" and c["world_size"] == 1 and c["bytes_gathered_per_rank_per_step"] > 0
     assert d["result"]["album"]["n_abs"] > 0
+
+
+def test_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` end to end: the launcher spawns two ranks, default workload for N > 1 is
+    config 4 (album tracks dealt round-robin), album exchange every step, max-over-ranks time, rank 0
+    prints.  Both ranks share the one GPU of the box, so the exchange runs over gloo (RCCL needs one
+    device per rank); the 8-GPU RCCL run is the driver's."""
+    d = _bench("--gpus", "2", "--backend", "gloo", "--same-gpu", "--tracks", "11", "--track-scale", "0.05",
+               "--steps", "4", "--warmup", "1")
+    assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("C4") and d["scaling"] == "strong"
+    assert d["config"]["tracks_this_rank"] == 6                       # tracks 0, 2, 4, 6, 8, 10
+    import bench
+    assert d["config"]["samples_per_step_all_ranks"] == sum(bench.c4_track_frames(t, scale=0.05) * 2 for t in range(11))
+    c = d["collective"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo" and c["bytes_gathered_per_rank_per_step"] > 0
+    assert abs(d["value"] - d["config"]["samples_per_step_all_ranks"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    assert d["result"]["album"]["n_abs"] > d["result"]["n_abs"] > 0
