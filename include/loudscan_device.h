@@ -109,8 +109,12 @@ const char *lgd_last_error(void);
  * the caller's stream has drained: do not overwrite or free a track buffer before
  * lgd_fetch, or order the writer behind the scans with lgd_join), "album_slots"
  * (short-term slots in album record 1, see the multi-GPU album below; 0 = this plan's own),
- * "tp_prune" (1 = the true-peak interpolator is evaluated only where it can exceed the peak
- * already found -- exact, default; 0 = everywhere: the reference mode of the pruning tests). */
+ * "tp_prune" (1 = the true-peak interpolator is evaluated only where it can exceed the track's
+ * sample peak -- exact, default; 0 = everywhere: the reference mode of the pruning tests),
+ * "album_world" (ranks the scratch of the multi-GPU album's loudness range is sized for, default 8),
+ * "strided" (3+ channel streams as one stereo-shaped workgroup per channel pair: 0 never, 1 where
+ * measured faster = 5 / 7 / 17+ channels, default, 2 always), "group_streams" (1 = the groups of a
+ * mixed-rate plan are launched on several streams at once; measured slower, default 0). */
 int lgd_set_param(lgd_ctx *ctx, const char *name, long value);
 
 /* Build the segment table + workspace for a batch of tracks (host work and

@@ -2,8 +2,10 @@
 //
 // What they replace (all third-party libebur128 work reached from
 // /root/reference/src/scan.c:448 and :294-303,:383-388):
-//   lgd_scan_kernel      E3 K-weighting (K2) + sample peak (K1) + E4 true peak
-//                        (K3) + the 100 ms partial sums behind E5/E6 (K4)
+//   lgd_scan_kernel        E3 K-weighting (K2) + sample peak (K1) + the 100 ms partial sums behind
+//                          E5/E6 (K4) + every chunk's largest |x| for the true-peak kernel
+//   lgd_peak_reduce_kernel per-channel sample peak of each track (the pruning bound)
+//   lgd_tp_kernel          E4 true peak (K3): the 4x / 2x interpolator where it can exceed that bound
 // (the gating / LRA / album epilogue kernels live in lgd_epilogue.hip)
 //
 // Parallelisation of the strictly sequential IIR:
@@ -40,8 +42,6 @@
 #include "lgd_internal.h"
 
 #define LGD_WAVE 64
-// entries (u16) of a wave's true-peak candidate queue in LDS, behind the staged tile
-#define LGD_TPQ_CAP 512
 // tiles whose chunk maxima travel in one 16-B store per lane (8 bf16 values)
 #define LGD_ROW_TILES 8
 
@@ -947,14 +947,13 @@ extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
   const int halo = 12;
   (void)tp;
   const bool planar = !generic;
-  const size_t queue = 0;
   if (planar) {
     const int pad = (chunk % 2 == 0) ? 1 : 0;
     const int plane = (halo + 4 + pad + LGD_WAVE * (chunk + pad) + 4 + 8 + 1) & ~1;
-    return (size_t)nch * plane * sizeof(float) + queue;
+    return (size_t)nch * plane * sizeof(float);
   }
   // (+8 frames: the software-pipelined reads fetch up to one step past the tile)
-  return ((size_t)(LGD_WAVE * chunk + halo + 8) * nch + 4) * sizeof(float) + queue;
+  return ((size_t)(LGD_WAVE * chunk + halo + 8) * nch + 4) * sizeof(float);
 }
 
 template <int C, int G, int TP, bool WIDE = false, bool STR = false>
