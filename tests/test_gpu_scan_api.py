@@ -255,3 +255,20 @@ def test_wav_with_unreliable_data_size(oracle, tmp_path, announced):
     r = scan.scan_get_track_result(0, 0.0)
     assert abs(r.track_loudness - ref["loudness"]) <= 1e-6 and abs(r.track_peak - ref["peak"]) <= 1e-4
     scan.scan_deinit()
+
+
+def test_more_devices_than_files(oracle, tmp_path, monkeypatch):
+    """Devices without a single file take part in the album exchange with empty records."""
+    from loudgain_amd import scan
+    paths = []
+    for i in range(2):
+        pcm = synth.track_numpy(48000 * (6 + 3 * i), 2, 48000, seed=90 + i, step_s=1.1)
+        paths.append(write_wav(str(tmp_path / ("m%d.wav" % i)), pcm, 48000))
+    one, peak1 = _session(paths, scan)
+    monkeypatch.setenv("LOUDSCAN_VIRTUAL_DEVICES", "5")
+    many, peakn = _session(paths, scan)
+    monkeypatch.delenv("LOUDSCAN_VIRTUAL_DEVICES")
+    assert peak1 == peakn
+    for a, b in zip(one, many):
+        for f in FIELDS:
+            assert close(a[f], b[f], 1e-9), (f, a[f], b[f])
