@@ -438,10 +438,8 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   static const int pref_51[] = {25, 45, 35, 49, 50, 0};
   static const int pref_5[] = {25, 35, 0};  // 5 planes: longer chunks spill 25+ registers at 3 waves per SIMD
   const bool multi = (nch >= 3 && nch <= 6) || nch == 8;  // planar specialisations exist
-  // (three planes with the chunk maxima of the true-peak path on top: C = 50 spills at 3 waves per
-  // SIMD, 38 % against 42 % at C = 25)
   const int *pref = nch <= 2 ? pref_fast
-                    : (nch == 5 ? pref_5 : (nch == 4 || (nch == 3 && !tp) ? pref_34 : (multi ? pref_51 : pref_many)));
+                    : (nch == 5 ? pref_5 : (nch == 4 || nch == 3 ? pref_34 : (multi ? pref_51 : pref_many)));
   const bool generic = nch > 2 && !multi;
   for (int pass = 0; pass < 2; ++pass)
     for (const int *p = pref; *p; ++p)
