@@ -263,89 +263,202 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
 // ---- E8: loudness range of the listed short-term energies in st[off, off+n).
 // Exact: libebur128 sorts and indexes; here the two order statistics are found
 // by an MSB-first radix select over the IEEE bit patterns (positive doubles
-// order like their bits), so no sort and no histogram quantisation.  Up to
-// LGD_LRA_CAP energies are staged in LDS once; longer inputs stream from L2.
-#define LGD_LRA_NT 256  // one wave per SIMD at 32 VGPRs: fits next to two 197-VGPR scan waves
-#define LGD_LRA_CAP 384   // doubles staged in LDS (3 KiB): small on purpose, so that the workgroup fits
-                          // next to the scan kernel it overlaps with (which leaves ~5 KB LDS per CU)
+// order like their bits), so no sort and no histogram quantisation.
+// One workgroup per list.  The list is read ONCE, into registers (thread t holds entries t,
+// t + 256, ...: up to 32 of them, LGD_LRA_BIG / 256); the 8-bit digit passes then run on
+// registers and two LDS histograms.  Leading digits shared by the smallest and the largest kept
+// energy are skipped (the sign / exponent byte always is).  (Before: every pass re-read the list
+// from L2, 14 dependent loads per thread for the one-hour track of C2 -- 37 us of a 330 us scan,
+// 67 us for a two-hour mono track.)
+#define LGD_LRA_NT 256  // one wave per SIMD: fits next to two ~150-VGPR scan waves
+#define LGD_LRA_RMAX (LGD_LRA_BIG / LGD_LRA_NT)
 
-__global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__restrict__ ranges,
-                                                            const double *__restrict__ st_base,
-                                                            double minus20, int skip_big) {
-  LGD_EPI_PRIO();
-  __shared__ double sh[LGD_LRA_NT / LGD_WAVE];
-  __shared__ double cache[LGD_LRA_CAP];
-  __shared__ unsigned hist[2][256];
-  __shared__ unsigned long long s_prefix[2];
-  __shared__ unsigned long long s_rank[2];
-  const LgdRange rg = ranges[blockIdx.x];
-  if (skip_big && rg.n > LGD_LRA_BIG) return;  // the lgd_lra_big_* kernels take these
-  const double *gv = st_base + rg.off;
+__device__ __forceinline__ double block_min_f64(double v, double *sh) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmin(v, __shfl_xor(v, d, LGD_WAVE));
+  const int w = threadIdx.x / LGD_WAVE, l = threadIdx.x % LGD_WAVE;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  double t = sh[0];
+#pragma unroll
+  for (int i = 1; i < LGD_LRA_NT / LGD_WAVE; ++i) t = fmin(t, sh[i]);
+  return t;
+}
+
+struct LgdLraShared {
+  double sh[LGD_LRA_NT / LGD_WAVE];
+  unsigned hist[2][256];
+  unsigned long long prefix[2];
+  unsigned long long rank[2];
+};
+
+// x[r] = entry tid + r * LGD_LRA_NT of the list (0.0 beyond its end; entries <= 0 are not listed
+// energies and are ignored, as in the reference's histogram walk)
+template <int R>
+__device__ __forceinline__ void lgd_lra_in_registers(const double *__restrict__ gv, int n_list, double minus20,
+                                                     double *__restrict__ out, LgdLraShared &S) {
   const int tid = threadIdx.x;
-  const bool in_lds = rg.n <= LGD_LRA_CAP;
-  if (in_lds)
-    for (long long i = tid; i < rg.n; i += LGD_LRA_NT) cache[i] = gv[i];
-  __syncthreads();
-#define LRA_AT(i) (in_lds ? cache[i] : gv[i])
-
+  double x[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tid + r * LGD_LRA_NT;
+    x[r] = i < n_list ? gv[i] : 0.0;
+  }
+  // (per-thread partials in list order with stride 256, then the fixed trees: the same order for
+  // every R, so the relative threshold does not depend on the list's length class)
   double cnt = 0.0, sum = 0.0;
-  for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {
-    const double x = LRA_AT(i);
-    if (x > 0.0) { cnt += 1.0; sum += x; }
-  }
-  const double n = block_sum_f64<LGD_LRA_NT>(cnt, sh);
-  const double S = block_sum_f64<LGD_LRA_NT>(sum, sh);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (x[r] > 0.0) { cnt += 1.0; sum += x[r]; }
+  const double n = block_sum_f64<LGD_LRA_NT>(cnt, S.sh);
+  const double tot = block_sum_f64<LGD_LRA_NT>(sum, S.sh);
   if (n == 0.0) {
-    if (tid == 0) *rg.out = 0.0;
+    if (tid == 0) *out = 0.0;
     return;
   }
-  const double power = S / n;
+  const double power = tot / n;
   const double integrated = minus20 * power;
+  // keep the energies at or above the relative threshold (everything dropped sorts below them)
   cnt = 0.0;
-  for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {
-    const double x = LRA_AT(i);
-    if (x > 0.0 && !(x < integrated)) cnt += 1.0;
+  double lo = HUGE_VAL, hi = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (x[r] > 0.0 && !(x[r] < integrated)) {
+      cnt += 1.0;
+      lo = fmin(lo, x[r]);
+      hi = fmax(hi, x[r]);
+    } else {
+      x[r] = 0.0;
+    }
   }
-  const double mrem = block_sum_f64<LGD_LRA_NT>(cnt, sh);
+  const double mrem = block_sum_f64<LGD_LRA_NT>(cnt, S.sh);
   if (mrem == 0.0) {
-    if (tid == 0) *rg.out = 0.0;
+    if (tid == 0) *out = 0.0;
     return;
   }
+  lo = block_min_f64(lo, S.sh);
+  hi = block_max_f64<LGD_LRA_NT>(hi, S.sh);
+  const unsigned long long klo = (unsigned long long)__double_as_longlong(lo),
+                           khi = (unsigned long long)__double_as_longlong(hi);
+  // digits (bytes, MSB first) on which every kept energy agrees
+  const int first = klo == khi ? 8 : (__clzll((long long)(klo ^ khi)) >> 3);
   if (tid == 0) {
-    const unsigned long long dropped = (unsigned long long)(n - mrem);
-    s_rank[0] = dropped + (unsigned long long)((mrem - 1.0) * 0.95 + 0.5);
-    s_rank[1] = dropped + (unsigned long long)((mrem - 1.0) * 0.1 + 0.5);
-    s_prefix[0] = s_prefix[1] = 0ull;
+    S.rank[0] = (unsigned long long)((mrem - 1.0) * 0.95 + 0.5);
+    S.rank[1] = (unsigned long long)((mrem - 1.0) * 0.1 + 0.5);
+    S.prefix[0] = S.prefix[1] = first == 0 ? 0ull : (klo & (~0ull << (64 - 8 * first)));
   }
   __syncthreads();
-  for (int pass = 0; pass < 8; ++pass) {
+  for (int pass = first; pass < 8; ++pass) {
     const int sh_bits = 56 - 8 * pass;
     const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (sh_bits + 8));
-    for (int i = tid; i < 512; i += LGD_LRA_NT) hist[i >> 8][i & 255] = 0u;
+    for (int i = tid; i < 512; i += LGD_LRA_NT) S.hist[i >> 8][i & 255] = 0u;
     __syncthreads();
-    const unsigned long long p0 = s_prefix[0], p1 = s_prefix[1];
-    for (long long i = tid; i < rg.n; i += LGD_LRA_NT) {
-      const double x = LRA_AT(i);
-      if (x > 0.0) {
-        const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+    const unsigned long long p0 = S.prefix[0], p1 = S.prefix[1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (x[r] > 0.0) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(x[r]);
         const unsigned dg = (unsigned)((key >> sh_bits) & 0xffu);
-        if ((key & himask) == p0) atomicAdd(&hist[0][dg], 1u);
-        if ((key & himask) == p1) atomicAdd(&hist[1][dg], 1u);
+        if ((key & himask) == p0) atomicAdd(&S.hist[0][dg], 1u);
+        if ((key & himask) == p1) atomicAdd(&S.hist[1][dg], 1u);
       }
     }
     __syncthreads();
     // waves 0 and 1 each locate their rank's digit: lane l owns bins 4l..4l+3
     if (tid < 2 * LGD_WAVE) {
       const int which = tid / LGD_WAVE, l = tid % LGD_WAVE;
-      const unsigned h0 = hist[which][4 * l], h1 = hist[which][4 * l + 1],
-                     h2 = hist[which][4 * l + 2], h3 = hist[which][4 * l + 3];
+      const unsigned h0 = S.hist[which][4 * l], h1 = S.hist[which][4 * l + 1],
+                     h2 = S.hist[which][4 * l + 2], h3 = S.hist[which][4 * l + 3];
+      unsigned incl = h0 + h1 + h2 + h3;
+      const unsigned own = incl;
+#pragma unroll
+      for (int d = 1; d < LGD_WAVE; d <<= 1) {
+        const unsigned up = __shfl_up(incl, d, LGD_WAVE);
+        if (l >= d) incl += up;
+      }
+      const unsigned long long r = S.rank[which];
+      const unsigned long long excl = incl - own;
+      if (excl <= r && r < incl) {  // exactly one lane
+        unsigned long long c = excl;
+        int dg = 4 * l;
+        if (c + h0 <= r) { c += h0; ++dg;
+          if (c + h1 <= r) { c += h1; ++dg;
+            if (c + h2 <= r) { c += h2; ++dg; } } }
+        S.rank[which] = r - c;
+        S.prefix[which] |= ((unsigned long long)dg) << sh_bits;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double h_en = __longlong_as_double((long long)S.prefix[0]);
+    const double l_en = __longlong_as_double((long long)S.prefix[1]);
+    *out = energy_to_loudness(h_en) - energy_to_loudness(l_en);
+  }
+}
+
+// the same select for a list of any length, streamed from memory in every pass
+__device__ __noinline__ void lgd_lra_streaming(const double *__restrict__ gv, long long n_list, double minus20,
+                                               double *__restrict__ out, LgdLraShared &S) {
+  const int tid = threadIdx.x;
+  double cnt = 0.0, sum = 0.0;
+  for (long long i = tid; i < n_list; i += LGD_LRA_NT) {
+    const double x = gv[i];
+    if (x > 0.0) { cnt += 1.0; sum += x; }
+  }
+  const double n = block_sum_f64<LGD_LRA_NT>(cnt, S.sh);
+  const double tot = block_sum_f64<LGD_LRA_NT>(sum, S.sh);
+  if (n == 0.0) {
+    if (tid == 0) *out = 0.0;
+    return;
+  }
+  const double power = tot / n;
+  const double integrated = minus20 * power;
+  cnt = 0.0;
+  for (long long i = tid; i < n_list; i += LGD_LRA_NT) {
+    const double x = gv[i];
+    if (x > 0.0 && !(x < integrated)) cnt += 1.0;
+  }
+  const double mrem = block_sum_f64<LGD_LRA_NT>(cnt, S.sh);
+  if (mrem == 0.0) {
+    if (tid == 0) *out = 0.0;
+    return;
+  }
+  if (tid == 0) {
+    const unsigned long long dropped = (unsigned long long)(n - mrem);
+    S.rank[0] = dropped + (unsigned long long)((mrem - 1.0) * 0.95 + 0.5);
+    S.rank[1] = dropped + (unsigned long long)((mrem - 1.0) * 0.1 + 0.5);
+    S.prefix[0] = S.prefix[1] = 0ull;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < 8; ++pass) {
+    const int sh_bits = 56 - 8 * pass;
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (sh_bits + 8));
+    for (int i = tid; i < 512; i += LGD_LRA_NT) S.hist[i >> 8][i & 255] = 0u;
+    __syncthreads();
+    const unsigned long long p0 = S.prefix[0], p1 = S.prefix[1];
+    for (long long i = tid; i < n_list; i += LGD_LRA_NT) {
+      const double x = gv[i];
+      if (x > 0.0) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+        const unsigned dg = (unsigned)((key >> sh_bits) & 0xffu);
+        if ((key & himask) == p0) atomicAdd(&S.hist[0][dg], 1u);
+        if ((key & himask) == p1) atomicAdd(&S.hist[1][dg], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * LGD_WAVE) {
+      const int which = tid / LGD_WAVE, l = tid % LGD_WAVE;
+      const unsigned h0 = S.hist[which][4 * l], h1 = S.hist[which][4 * l + 1],
+                     h2 = S.hist[which][4 * l + 2], h3 = S.hist[which][4 * l + 3];
       unsigned long long incl = (unsigned long long)h0 + h1 + h2 + h3;
 #pragma unroll
       for (int d = 1; d < LGD_WAVE; d <<= 1) {
         const unsigned long long up = __shfl_up(incl, d, LGD_WAVE);
         if (l >= d) incl += up;
       }
-      const unsigned long long r = s_rank[which];
+      const unsigned long long r = S.rank[which];
       const unsigned long long excl = incl - ((unsigned long long)h0 + h1 + h2 + h3);
       if (excl <= r && r < incl) {  // exactly one lane
         unsigned long long c = excl;
@@ -353,18 +466,39 @@ __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__r
         if (c + h0 <= r) { c += h0; ++dg;
           if (c + h1 <= r) { c += h1; ++dg;
             if (c + h2 <= r) { c += h2; ++dg; } } }
-        s_rank[which] = r - c;
-        s_prefix[which] |= ((unsigned long long)dg) << sh_bits;
+        S.rank[which] = r - c;
+        S.prefix[which] |= ((unsigned long long)dg) << sh_bits;
       }
     }
     __syncthreads();
   }
-#undef LRA_AT
   if (tid == 0) {
-    const double h_en = __longlong_as_double((long long)s_prefix[0]);
-    const double l_en = __longlong_as_double((long long)s_prefix[1]);
-    *rg.out = energy_to_loudness(h_en) - energy_to_loudness(l_en);
+    const double h_en = __longlong_as_double((long long)S.prefix[0]);
+    const double l_en = __longlong_as_double((long long)S.prefix[1]);
+    *out = energy_to_loudness(h_en) - energy_to_loudness(l_en);
   }
+}
+
+__global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__restrict__ ranges,
+                                                            const double *__restrict__ st_base,
+                                                            double minus20, int skip_big) {
+  LGD_EPI_PRIO();
+  __shared__ LgdLraShared S;
+  const LgdRange rg = ranges[blockIdx.x];
+  const double *gv = st_base + rg.off;
+  if (rg.n > LGD_LRA_BIG) {
+    // the lgd_lra_big_* kernels take these; without their scratch (a distributed album longer
+    // than the plan provided for) the list streams from L2 once per pass
+    if (!skip_big) lgd_lra_streaming(gv, rg.n, minus20, rg.out, S);
+    return;
+  }
+  const int n = (int)rg.n;
+  if (n <= 1 * LGD_LRA_NT) lgd_lra_in_registers<1>(gv, n, minus20, rg.out, S);
+  else if (n <= 2 * LGD_LRA_NT) lgd_lra_in_registers<2>(gv, n, minus20, rg.out, S);
+  else if (n <= 4 * LGD_LRA_NT) lgd_lra_in_registers<4>(gv, n, minus20, rg.out, S);
+  else if (n <= 8 * LGD_LRA_NT) lgd_lra_in_registers<8>(gv, n, minus20, rg.out, S);
+  else if (n <= 16 * LGD_LRA_NT) lgd_lra_in_registers<16>(gv, n, minus20, rg.out, S);
+  else lgd_lra_in_registers<LGD_LRA_RMAX>(gv, n, minus20, rg.out, S);
 }
 
 // ---- E8 for LONG lists (an album of hundreds of tracks: ~2.3e5 short-term energies in C4, where the
