@@ -112,8 +112,9 @@ const char *lgd_last_error(void);
  * "tp_prune" (1 = the true-peak interpolator is evaluated only where it can exceed the track's
  * sample peak -- exact, default; 0 = everywhere: the reference mode of the pruning tests),
  * "album_world" (ranks the scratch of the multi-GPU album's loudness range is sized for, default 8),
- * "strided" (3+ channel streams as one stereo-shaped workgroup per channel pair: 0 never, 1 where
- * measured faster = 5 / 7 / 17+ channels, default, 2 always), "group_streams" (1 = the groups of a
+ * "strided" (3+ channel streams as one workgroup per channel pair or triple of every segment: 0 never,
+ * 1 where measured faster = pairs for 5 / 7 / 17+ channels, triples for 5.1, default; 2 pairs always;
+ * 3 triples wherever the channel count divides by three), "group_streams" (1 = the groups of a
  * mixed-rate plan are launched on several streams at once; measured slower, default 0). */
 int lgd_set_param(lgd_ctx *ctx, const char *name, long value);
 

@@ -408,7 +408,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "album_slots")) c->p_album_slots = value;  // short-term slots of album record 1
   else if (!strcmp(name, "tp_prune")) c->p_tp_prune = value;  // 0: evaluate every interpolator window
   else if (!strcmp(name, "group_streams")) { c->p_group_streams = value; return LGD_OK; }  // 0: groups one after the other
-  else if (!strcmp(name, "strided")) c->p_strided = value;  // channel-pair workgroups: 0 never, 1 where measured faster, 2 every 3+ channel layout
+  else if (!strcmp(name, "strided")) c->p_strided = value;  // channel pair / triple workgroups: 0 never, 1 where measured faster, 2 pairs for every 3+ channel layout, 3 triples wherever the count divides
   else if (!strcmp(name, "album_world")) c->p_album_world = value ? value : 8;  // ranks the multi-GPU album scratch is sized for
   else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
   c->planned = false;
@@ -438,13 +438,16 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
   static const int pref_51[] = {25, 45, 35, 49, 50, 0};
   static const int pref_5[] = {25, 35, 0};  // 5 planes: longer chunks spill 25+ registers at 3 waves per SIMD
   const bool multi = (nch >= 3 && nch <= 6) || nch == 8;  // planar specialisations exist
+  // (eight planes: one workgroup per CU either way, so the long chunk wins -- 0.362 ms against 0.425 ms for
+  // 345.6 M samples at 48 kHz with true peak; six planes at C = 50 need more than the 168 VGPRs of
+  // three waves per SIMD and lose, 0.47 against 0.39 ms)
   const int *pref = nch <= 2 ? pref_fast
-                    : (nch == 5 ? pref_5 : (nch == 4 || nch == 3 ? pref_34 : (multi ? pref_51 : pref_many)));
+                    : (nch == 5 ? pref_5 : (nch == 4 || nch == 3 || nch == 8 ? pref_34 : (multi ? pref_51 : pref_many)));
   const bool generic = nch > 2 && !multi;
   for (int pass = 0; pass < 2; ++pass)
     for (const int *p = pref; *p; ++p)
       if (s100 % *p == 0 &&
-          lgd_scan_lds_bytes(*p, (int)nch, tp, generic) <= (pass ? lds_cap : (multi ? lds_cap / 2 : lds_cap / 4)))
+          lgd_scan_lds_bytes(*p, (int)nch, tp, generic) <= (pass || nch == 8 ? lds_cap : (multi ? lds_cap / 2 : lds_cap / 4)))
         return *p;
   return 0;
 }
@@ -558,20 +561,28 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   // tools/rate_sweep.py, "strided" 2 = every layout): 5 channels 40 % of the HBM peak instead of
   // 27 %, 7 channels 34 vs 30 %, 24 channels 12 vs 10 %; but 3 / 4 / 5.1 / 7.1 / 12 channels 38 / 52 /
   // 44 / 29 / 19 % against 54 / 56 / 45 / 41 / 42 % on the planar kernels.
-  auto strided_for = [&](unsigned rate, unsigned ch) -> bool {
-    if (!c->p_strided || ch < 3) return false;
-    if (c->p_strided == 1 && !(ch == 5 || ch == 7 || ch > LGD_GROUP_CH)) return false;
+  // 5.1 (six channels) goes out as two channel TRIPLES: three-wave workgroups spread evenly over a
+  // CU's SIMDs (four per CU at C = 50), the planar kernel's six-wave workgroups do not (two per CU
+  // land 4 / 4 / 2 / 2 waves on a quarter of the CUs, tools/hwid_probe.py).
+  // Returns the channels per workgroup: 0 = not strided, 2 = pairs, 3 = triples.
+  auto strided_for = [&](unsigned rate, unsigned ch) -> unsigned {
+    if (!c->p_strided || ch < 3) return 0;
     const int tp_ = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(rate) : 0;
-    return pick_chunk(c->p_chunk, (int)((rate + 5) / 10), 2, tp_) != 0;
+    const int s100_ = (int)((rate + 5) / 10);
+    if ((c->p_strided == 3 ? ch % 3 == 0 : (c->p_strided == 1 && ch == 6)) && pick_chunk(c->p_chunk, s100_, 3, tp_) != 0)
+      return 3;
+    if (c->p_strided != 2 && !(ch == 5 || ch == 7 || ch > LGD_GROUP_CH)) return 0;
+    return pick_chunk(c->p_chunk, s100_, 2, tp_) != 0 ? 2 : 0;
   };
   for (uint32_t t = 0; t < n; ++t) {
     const unsigned ch = tracks[t].channels;
-    const uint64_t mult = strided_for(tracks[t].rate, ch) ? (ch + 1) / 2 : 1;  // one segment set per pair
+    const unsigned sw = strided_for(tracks[t].rate, ch);
+    const uint64_t mult = sw ? (ch + sw - 1) / sw : 1;  // one segment set per pair / triple
     key_sb[RC{tracks[t].rate, ch}] += (uint64_t)c->meta[t].n_sb * mult;
   }
   for (const auto &kv : key_sb) {
-    const bool str = strided_for(kv.first.rate, kv.first.ch);
-    const unsigned k = str ? 2u : std::min<unsigned>(kv.first.ch, LGD_GROUP_CH);
+    const unsigned str = strided_for(kv.first.rate, kv.first.ch);
+    const unsigned k = str ? str : std::min<unsigned>(kv.first.ch, LGD_GROUP_CH);
     const unsigned per_cu = k <= 2 ? std::max(1u, (unsigned)c->p_waves_per_cu / k)
                                    : (k > 8 ? std::max(1u, 16u / k) : std::max(1u, 12u / k));
     const uint64_t slots = (uint64_t)c->n_cu * per_cu;
@@ -592,11 +603,13 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     m.n_seg = (int)nseg;
     m.peak_off = (long long)c->total_peak_floats;
     c->total_peak_floats += nseg * 2ull * tr.channels;
-    const bool strided = strided_for(tr.rate, tr.channels);
+    const unsigned strided = strided_for(tr.rate, tr.channels);
     std::vector<unsigned> ch0s;  // first channel of every workgroup set of this track
     if (strided) {
-      for (unsigned a = 0; a + 1 < tr.channels; a += 2) ch0s.push_back(a);
-      if (tr.channels & 1) ch0s.push_back(tr.channels - 2);  // (channel nch-2 twice: same results, one launch)
+      // (a last pair / triple that does not fit overlaps its neighbour: those channels are computed
+      // twice, with the same results, in one launch)
+      for (unsigned a = 0; a + strided <= tr.channels; a += strided) ch0s.push_back(a);
+      if (tr.channels % strided) ch0s.push_back(tr.channels - strided);
     } else {
       for (unsigned a = 0; a < tr.channels; a += LGD_GROUP_CH) ch0s.push_back(a);
     }
@@ -604,7 +617,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     size_t pair_group = 0;
     for (size_t pi = 0; pi < ch0s.size(); ++pi) {
       const unsigned ch0 = ch0s[pi];
-      const unsigned g_nch = strided ? 2u : std::min<unsigned>(LGD_GROUP_CH, tr.channels - ch0);
+      const unsigned g_nch = strided ? strided : std::min<unsigned>(LGD_GROUP_CH, tr.channels - ch0);
       const Key key{tr.rate, tr.channels, g_nch};
       auto it = group_of.find(key);
       if (it == group_of.end()) {
@@ -613,8 +626,8 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         g.nch = g_nch;
         g.nch_total = tr.channels;
         g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
-        g.strided = strided;
-        g.chunk = strided ? pick_chunk(c->p_chunk, s100, 2, g.tp)
+        g.strided = strided != 0;
+        g.chunk = strided ? pick_chunk(c->p_chunk, s100, strided, g.tp)
                           : (((g_nch <= 6 || g_nch == 8) && g_nch == tr.channels)
                                  ? pick_chunk(c->p_chunk, s100, g_nch, g.tp) : 0);
         // fast kernels: mono / stereo with a chunk that divides the sub-block; anything else

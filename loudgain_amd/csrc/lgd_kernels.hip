@@ -179,7 +179,7 @@ struct ScanCfg {
 // short chunks)
 // WIDE (run-time-G kernel only): up to 16 waves per workgroup -> <= 128 VGPRs;
 // otherwise up to 8 waves (<= 256 VGPRs, no spills).
-// STR (G = 1 or 2 only): the workgroup takes channels [sg.ch0, sg.ch0 + G) of a stream of sg.nch_total
+// STR (G = 1, 2 or 3 only): the workgroup takes channels [sg.ch0, sg.ch0 + G) of a stream of sg.nch_total
 // interleaved channels -- one frame per lane and load (a dword or an aligned pair), sibling
 // workgroups of the other channel pairs read the same lines through L2 / Infinity Cache.  Every
 // layout then runs the mono / stereo kernel's long chunks (a six-plane tile of C = 75 would not
@@ -205,13 +205,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   const int ch = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = LGD_WAVE * nch;
   const LgdSeg sg = segs[blockIdx.x];
-  static_assert(!STR || G == 1 || G == 2, "strided variant: one or two channels per workgroup");
+  static_assert(!STR || G == 1 || G == 2 || G == 3, "strided variant: one to three channels per workgroup");
   const int shift = (STR || (G == 0 && sg.nch_total != (G ? G : nch_rt))) ? 0 : (int)((sg.f0 * nch) & 3);
   const long long n_frames = sg.n_frames;
   const int nvec = ((K::TILE_F + K::HALO) * nch + 4) >> 2;  // 16-B vectors per tile
   // frame slot of tile frame -HALO inside a plane
   using LL = LdsLayout<C, G>;
-  const int slot_shift = LL::SHIFT_WHOLE ? shift / (G ? G : 1) : 1;
+  const int slot_shift = STR ? 0 : (LL::SHIFT_WHOLE ? shift / (G ? G : 1) : 1);  // (strided staging: frame slots as they are)
   // vector i of a thread is in range for EVERY thread when this holds (compile-time
   // for the fixed-channel-count kernels: no exec masking around full vectors)
 #define LGD_VEC_ALWAYS(i_) (G != 0 && (LGD_WAVE * G) * ((i_) + 1) <= (((K::TILE_F + K::HALO) * G + 4) >> 2))
@@ -283,10 +283,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   constexpr int NFR = K::TILE_F + K::HALO;                              // frames staged per tile
   constexpr int NVS = STR ? (NFR + LGD_WAVE * (G ? G : 1) - 1) / (LGD_WAVE * (G ? G : 1)) : 1;
   typedef const f32x2 LGD_GLOBAL *gvec2_ptr;
-  f32x2 pfs[NVS];
+  typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+  typedef const f32x3u LGD_GLOBAL *gvec3_ptr;
+  f32x4 pfs[NVS];  // (.w unused; .z only by channel triples)
 #pragma unroll
-  for (int i = 0; i < NVS; ++i) pfs[i] = (f32x2){0.f, 0.f};
-  // (an aligned pair of channels is one 8-B load; odd channel counts take two dwords)
+  for (int i = 0; i < NVS; ++i) pfs[i] = (f32x4)(0.f);
+  // (an aligned pair of channels is one 8-B load; odd channel counts take two dwords; a triple is
+  // one 12-B load)
   const bool aligned2 = STR && G == 2 && !((nch_tot | ch0) & 1);
 #define LGD_PREFETCH_STR(kk)                                                            \
   do {                                                                                  \
@@ -300,8 +303,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         gflt_ptr src_i_ = src_ + (long long)(nthreads * i_) * nch_tot;                  \
         asm volatile("" : "+s"(src_i_));                                                \
         if (nthreads * (i_ + 1) <= NFR || tid + nthreads * i_ < NFR) {                  \
-          if (G == 2 && aligned2) pfs[i_] = *(gvec2_ptr)(src_i_ + lo_);                 \
-          else {                                                                        \
+          if (G == 3) {                                                                 \
+            const f32x3u t_ = *(gvec3_ptr)(src_i_ + lo_);                               \
+            pfs[i_].x = t_.x; pfs[i_].y = t_.y; pfs[i_].z = t_.z;                       \
+          } else if (G == 2 && aligned2) {                                              \
+            const f32x2 t_ = *(gvec2_ptr)(src_i_ + lo_);                                \
+            pfs[i_].x = t_.x; pfs[i_].y = t_.y;                                         \
+          } else {                                                                      \
             pfs[i_].x = src_i_[lo_];                                                    \
             if (G == 2) pfs[i_].y = src_i_[lo_ + 1u];                                   \
           }                                                                             \
@@ -343,17 +351,18 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     } while (0)
     if constexpr (STR) {
       // frame fr (0 = tile frame -HALO) of plane c sits at fr + PAD * floor((fr - HALO + C) / C)
-#define LGD_STORE_FRAME(fr_, a_, b_)                                                    \
+#define LGD_STORE_FRAME(fr_, a_, b_, c_)                                                \
       do {                                                                              \
         const int at_ = (fr_) + LL::PAD * (int)((unsigned)((fr_) - K::HALO + C) / (unsigned)C); \
         lds[at_] = (a_);                                                                \
-        if (G == 2) lds[PLANE + at_] = (b_);                                            \
+        if (G >= 2) lds[PLANE + at_] = (b_);                                            \
+        if (G >= 3) lds[2 * PLANE + at_] = (c_);                                        \
       } while (0)
       if (pf_valid && !(dbg & 64)) {
 #pragma unroll
         for (int i = 0; i < NVS; ++i) {
           const int fr = tid + nthreads * i;
-          if (nthreads * (i + 1) <= NFR || fr < NFR) LGD_STORE_FRAME(fr, pfs[i].x, pfs[i].y);
+          if (nthreads * (i + 1) <= NFR || fr < NFR) LGD_STORE_FRAME(fr, pfs[i].x, pfs[i].y, pfs[i].z);
         }
       } else if (!(dbg & 1) && !(dbg & 64)) {  // a tile at a track edge: frames outside the track are zero
         const gflt_ptr gp = (gflt_ptr)sg.pcm + ch0;
@@ -361,8 +370,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           const long long f = tb - K::HALO + fr;
           const bool in = f >= 0 && f < n_frames;
           const float a = in ? gp[f * nch_tot] : 0.f;
-          const float b = (in && G == 2) ? gp[f * nch_tot + 1] : 0.f;
-          LGD_STORE_FRAME(fr, a, b);
+          const float b = (in && G >= 2) ? gp[f * nch_tot + 1] : 0.f;
+          const float c = (in && G >= 3) ? gp[f * nch_tot + 2] : 0.f;
+          LGD_STORE_FRAME(fr, a, b, c);
         }
       }
 #undef LGD_STORE_FRAME
@@ -991,6 +1001,13 @@ static hipError_t launch_scan_strided(int nch, int tp, const LgdSeg *segs, int n
   if (nch == 1) {
     if (tp) return launch_scan_t<C, 1, 4, false, true>(segs, n_seg, F, nch, s);
     return launch_scan_t<C, 1, 0, false, true>(segs, n_seg, F, nch, s);
+  }
+  if (nch == 3) {
+    if constexpr (C <= 50) {  // (three planes: the chunk lengths the three-channel kernel is built for)
+      if (tp) return launch_scan_t<C, 3, 4, false, true>(segs, n_seg, F, nch, s);
+      return launch_scan_t<C, 3, 0, false, true>(segs, n_seg, F, nch, s);
+    }
+    return hipErrorInvalidValue;
   }
   if (nch != 2) return hipErrorInvalidValue;
   if (tp) return launch_scan_t<C, 2, 4, false, true>(segs, n_seg, F, nch, s);

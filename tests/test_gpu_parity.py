@@ -552,3 +552,31 @@ def test_channel_pair_workgroups_on_any_layout(oracle, rate, nch):
     np.testing.assert_allclose(ea, eb, rtol=energy_rtol(rate))   # (other chunk length: other rounding)
     assert np.array_equal(spa, spb) and np.array_equal(tpa, tpb)
     assert (a["n_abs"], a["n_rel"], a["n_st"]) == (b["n_abs"], b["n_rel"], b["n_st"])
+
+
+@pytest.mark.parametrize("rate,nch", [(48000, 3), (48000, 6), (44100, 6), (96000, 6), (192000, 6), (48000, 9), (32000, 12),
+                                      (48000, 7), (48000, 8)])
+def test_channel_triple_workgroups(oracle, rate, nch):
+    """"strided" 3: streams whose channel count divides by three as three-wave workgroups, one per channel
+    TRIPLE of the interleaved stream (the default does this for 5.1: two triples, the LFE in the second);
+    other counts fall back to what the default does.  Same results as the many-plane kernels ("strided" 0)."""
+    from loudgain_amd.device import DeviceScanner
+    frames = int(rate * 6.1) + 29
+    pcm = synth.track_numpy(frames, nch, rate, seed=700 + nch, step_s=1.1)
+    gains = np.array([1.0, 0.7, 0.5, 1.3, 0.9, 0.6, 1.1, 0.8] * 2)[:nch].astype(np.float32)
+    pcm = synth.snap_s16_numpy(pcm * gains[None, :])
+    ref = oracle.scan_track(pcm, rate)
+    out = []
+    for mode in (3, 0):
+        sc = DeviceScanner(0)
+        sc.set_param("strided", mode)
+        (got,), _ = sc.scan([to_dev(pcm)], rate)
+        check_track(got, ref, rate=rate)
+        sp, tp = sc.channel_peaks(0, nch)
+        np.testing.assert_allclose(tp, np.asarray(ref["true_peak"]), atol=1e-4, rtol=0)
+        out.append((got, sc.subblock_energies(0), sp, tp))
+        sc.close()
+    (a, ea, spa, tpa), (b, eb, spb, tpb) = out
+    np.testing.assert_allclose(ea, eb, rtol=energy_rtol(rate))
+    assert np.array_equal(spa, spb) and np.array_equal(tpa, tpb)
+    assert (a["n_abs"], a["n_rel"], a["n_st"]) == (b["n_abs"], b["n_rel"], b["n_st"])
