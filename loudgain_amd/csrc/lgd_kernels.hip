@@ -974,7 +974,7 @@ extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
 // workgroups -- this kernel is bound by fp64 issue per SIMD, so the kernel then takes as long as its
 // three-wave SIMDs: 0.334 ms instead of 0.283 ms (three channels: 4 waves on some SIMDs, +7 %).  A
 // grid of empty one-wave workgroups in front restores the even placement (1024, 2048 and 4096
-// workgroups measured alike; two-wave workgroups do not); it costs ~2 us.  Two-, four- and eight-wave
+// workgroups measured alike; two-wave workgroups do not); 1024 cost ~3 us.  Two-, four- and eight-wave
 // workgroups are placed evenly whatever ran before; six-wave workgroups (5.1) are not, with or
 // without this (two per CU land 4/4/2/2 on a quarter of the CUs).
 __global__ void lgd_prime_kernel() {}
@@ -983,7 +983,7 @@ template <int C, int G, int TP, bool WIDE = false, bool STR = false>
 static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, const LgdFilt *F, int nch,
                                 hipStream_t s) {
   const size_t lds_bytes = lgd_scan_lds_bytes(C, nch, TP, G == 0);
-  if constexpr (G == 1 || G == 3) hipLaunchKernelGGL(lgd_prime_kernel, dim3(2048), dim3(LGD_WAVE), 0, s);
+  if constexpr (G == 1 || G == 3) hipLaunchKernelGGL(lgd_prime_kernel, dim3(1024), dim3(LGD_WAVE), 0, s);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)lgd_scan_kernel<C, G, TP, WIDE, STR>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
