@@ -227,8 +227,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 
   const double ra1 = F.ra[0], ra2 = F.ra[1], pa1 = F.pa[0], pa2 = F.pa[1];
   const double c1 = F.pbn[0], c2 = F.pbn[1];
-  const double alpha = F.alpha, beta = F.beta, gamma_ = F.gamma, inv_alpha = F.inv_alpha,
-               inv_beta = F.inv_beta, dcg = F.dc, pb0sq = F.pb0sq;
+  // (alpha, beta, gamma, 1/alpha, 1/beta, dc and pb0^2 are used once per tile: read through the
+  // per-tile constants pointer where they are needed, not held in SGPRs across the tile loop)
   const int lps = F.lps;
   const int pskip = F.pskip;
   const int s100 = F.s100;
@@ -249,6 +249,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // them which interpolator outputs can matter and evaluates those)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   u32x4 mc_rows = (u32x4)(0u);  // this lane's chunk maxima of the last 8 tiles (bf16, newest on top)
+  // where this lane's next record goes: [group of 8 tiles][channel][lane] (a per-lane pointer in
+  // VGPRs: the scalar form kept the base and the group index live in SGPRs through the tile loop)
+  u32x4 LGD_GLOBAL *row_p = (u32x4 LGD_GLOBAL *)sg.tp_rows + (ch * LGD_WAVE + lane);
 
   const int n_main = sg.n_tiles;
 
@@ -417,8 +420,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     if constexpr (TP != 0) {
       // (behind the loads just issued, and only one store per LGD_ROW_TILES tiles: a vector store
       // costs the wave ~0.4 us here whatever its width -- one per tile was 10 % of the kernel)
-      if (k > 0 && (k & (LGD_ROW_TILES - 1)) == 0)
-        ((u32x4 LGD_GLOBAL *)sg.tp_rows)[((size_t)((k >> 3) - 1) * nch + ch) * LGD_WAVE + lane] = mc_rows;
+      if (k > 0 && (k & (LGD_ROW_TILES - 1)) == 0) {
+        *row_p = mc_rows;
+        row_p += nch * LGD_WAVE;
+      }
     }
     __builtin_amdgcn_s_setprio(LGD_PRIO_A);
 
@@ -488,9 +493,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         const auto *g0 = Fk->gC[0];
         const auto *g1 = Fk->gC[1];
         z[0] = fma(g1[0], dw1, fma(g0[0], dw0, q1));
-        z[1] = fma(g1[1], dw1, fma(g0[1], dw0, alpha * fma(-beta, q2, q1)));
-        z[2] = fma(g1[2], dw1, fma(g0[2], dw0, gamma_ * p1));
-        z[3] = fma(g1[3], dw1, fma(g0[3], dw0, gamma_ * p2));
+        z[1] = fma(g1[1], dw1, fma(g0[1], dw0, Fk->alpha * fma(-Fk->beta, q2, q1)));
+        z[2] = fma(g1[2], dw1, fma(g0[2], dw0, Fk->gamma * p1));
+        z[3] = fma(g1[3], dw1, fma(g0[3], dw0, Fk->gamma * p2));
       }
 
       // (latency-bound section: issue priority over the SIMD's other wave, which is most
@@ -551,9 +556,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         cin[r] = __shfl(z[r], LGD_WAVE - 1, LGD_WAVE);
       }
       qs[0] = sv[0];
-      qs[1] = fma(-inv_alpha, sv[1], sv[0]) * inv_beta;
-      ps[0] = sv[2] * dcg;
-      ps[1] = sv[3] * dcg;
+      qs[1] = fma(-Fk->inv_alpha, sv[1], sv[0]) * Fk->inv_beta;
+      ps[0] = sv[2] * Fk->dc;
+      ps[1] = sv[3] * Fk->dc;
       __builtin_amdgcn_s_setprio(LGD_PRIO_C);
     }
 
@@ -660,7 +665,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           const bool mine = rel >= 0 && rel < lps;
           acc += mine ? e : 0.0;
           if (k * LGD_WAVE + LGD_WAVE >= cur_q + lps) {  // `cur` ends in this tile
-            const double tot = wave_sum_f64(acc) * pb0sq;
+            const double tot = wave_sum_f64(acc) * Fk->pb0sq;
             if (lane == 0 && cur < sg.n_sb)
               ((double LGD_GLOBAL *)sg.e_out)[(long long)(ch0 + ch) * sg.e_ch_stride + cur] = tot;
             acc = 0.0;
@@ -677,7 +682,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         for (;;) {
           acc += (sb_l == cur ? e : 0.0) + (sb_l + 1 == cur ? e_next : 0.0);
           if (tile_end >= (unsigned)(cur + 1) * (unsigned)s100) {  // `cur` ends in this tile
-            const double tot = wave_sum_f64(acc) * pb0sq;
+            const double tot = wave_sum_f64(acc) * Fk->pb0sq;
             if (lane == 0 && cur < sg.n_sb)
               ((double LGD_GLOBAL *)sg.e_out)[(long long)(ch0 + ch) * sg.e_ch_stride + cur] = tot;
             acc = 0.0;
@@ -691,8 +696,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   }
 
   if constexpr (TP != 0) {
-    if (n_main > 0)  // the last group: n_main mod 8 tiles (8 if 0), newest on top
-      ((u32x4 LGD_GLOBAL *)sg.tp_rows)[((size_t)((n_main - 1) >> 3) * nch + ch) * LGD_WAVE + lane] = mc_rows;
+    if (n_main > 0) *row_p = mc_rows;  // the last group: n_main mod 8 tiles (8 if 0), newest on top
   }
   {
     const float s = wave_max_f32(pk_s);
