@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--warm-subblocks", type=int, default=-1)
     ap.add_argument("--no-tp-prune", action="store_true")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
+                    help="any engine parameter (lgd_set_param), e.g. merge_launches=0")
     ap.add_argument("--debug", type=int, default=0, help="kernel floor measurement: 1 no loads, 2 no arithmetic")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal of the N>1 path on one GPU: RCCL group of one rank, album exchange every step")
@@ -262,6 +264,9 @@ class Runner:
             sc.set_param("debug", a.debug)
         if a.no_tp_prune:
             sc.set_param("tp_prune", 0)
+        for kv in a.param:
+            name, value = kv.split("=")
+            sc.set_param(name, int(value))
         self.stream = torch.cuda.Stream(device=self.dev)
 
     def kernel_stats(self, tracks, rates, true_peak, album, launches=64, settle=300):

@@ -114,7 +114,9 @@ const char *lgd_last_error(void);
  * "album_world" (ranks the scratch of the multi-GPU album's loudness range is sized for, default 8),
  * "strided" (3+ channel streams as one workgroup per channel pair or triple of every segment: 0 never,
  * 1 where measured faster = pairs for 5 / 7 / 17+ channels, triples for 5.1, default; 2 pairs always;
- * 3 triples wherever the channel count divides by three), "group_streams" (1 = the groups of a
+ * 3 triples wherever the channel count divides by three), "merge_launches" (1, default: the (rate, channels) groups of a plan that run the same kernel
+ * instance -- e.g. its 48, 96 and 192 kHz stereo tracks -- are scanned by one launch, sized to fill the GPU
+ * together; 0: one launch per group), "group_streams" (1 = the groups of a
  * mixed-rate plan are launched on several streams at once; measured slower, default 0). */
 int lgd_set_param(lgd_ctx *ctx, const char *name, long value);
 

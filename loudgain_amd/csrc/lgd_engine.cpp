@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -23,7 +24,7 @@
 extern "C" const int lgd_chunk_table[];
 extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic);
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, const LgdSeg *segs,
-                                      int n_seg, const LgdFilt *F, hipStream_t s);
+                                      int n_seg, hipStream_t s);
 extern "C" hipError_t lgd_launch_peak_reduce(const LgdTrackMeta *meta, int n_tracks, const float *peaks,
                                              float *hint, hipStream_t s);
 extern "C" hipError_t lgd_launch_tp(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
@@ -218,7 +219,7 @@ static float interp_prune_factor(int factor) {
 }
 
 // ------------------------------------------------------------------ context --
-struct Group {  // tracks sharing (rate, channels) -> one scan launch
+struct Group {  // tracks sharing (rate, channels, channels per workgroup): one set of kernel constants
   unsigned rate, nch, nch_total;  // nch: channels (waves) per workgroup
   int chunk, tp;
   bool generic;
@@ -226,6 +227,15 @@ struct Group {  // tracks sharing (rate, channels) -> one scan launch
   LgdFilt F;
   size_t seg_begin, seg_count;
   int rows_max;  // most true-peak candidate rows (tiles x channels) of any of its segments
+  size_t launch;  // the scan launch its segments go out with
+};
+// One lgd_scan_kernel launch: the groups that run the same kernel instance (chunk, waves per workgroup,
+// staging mode) -- e.g. the 48, 96 and 192 kHz stereo tracks of a plan (C = 75 for all three); the
+// constants differ per segment (LgdSeg::filt).
+struct Launch {
+  int chunk, nch, tp, mode;  // tp: some group of it has an interpolator (the kernel records chunk maxima)
+  size_t seg_begin, seg_count;
+  std::vector<size_t> groups;
 };
 static const size_t MAX_GROUPS = 64;  // distinct (rate, channels) pairs per plan
 static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at most
@@ -233,7 +243,7 @@ static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at m
 struct lgd_ctx {
   int device = 0;
   long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 0,
-       p_album_slots = 0, p_tp_prune = 1, p_album_world = 8, p_group_streams = 0, p_strided = 1;
+       p_album_slots = 0, p_tp_prune = 1, p_album_world = 8, p_group_streams = 0, p_strided = 1, p_merge = 1;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -291,7 +301,7 @@ struct lgd_ctx {
   static const int GSTREAMS = 3;   // extra streams the groups of a mixed plan are launched on
   hipStream_t gstream[GSTREAMS] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_gjoin[GSTREAMS] = {nullptr, nullptr, nullptr};
-  std::vector<size_t> group_order;  // launch order of the groups: largest first
+  std::vector<Launch> launches;     // scan launches, largest first
   LgdSlice *d_slices = nullptr;
   LgdFilt *d_filt = nullptr;  // [MAX_GROUPS] per-group kernel constants
   LgdTrackMeta *d_meta = nullptr;
@@ -408,6 +418,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "album_slots")) c->p_album_slots = value;  // short-term slots of album record 1
   else if (!strcmp(name, "tp_prune")) c->p_tp_prune = value;  // 0: evaluate every interpolator window
   else if (!strcmp(name, "group_streams")) { c->p_group_streams = value; return LGD_OK; }  // 0: groups one after the other
+  else if (!strcmp(name, "merge_launches")) c->p_merge = value;  // 1: groups that share a kernel instance go out in one launch
   else if (!strcmp(name, "strided")) c->p_strided = value;  // channel pair / triple workgroups: 0 never, 1 where measured faster, 2 pairs for every 3+ channel layout, 3 triples wherever the count divides
   else if (!strcmp(name, "album_world")) c->p_album_world = value ? value : 8;  // ranks the multi-GPU album scratch is sized for
   else return fail(LGD_EINVAL, "lgd_set_param: unknown parameter '%s'", name);
@@ -580,18 +591,66 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     const uint64_t mult = sw ? (ch + sw - 1) / sw : 1;  // one segment set per pair / triple
     key_sb[RC{tracks[t].rate, ch}] += (uint64_t)c->meta[t].n_sb * mult;
   }
+  // The kernel instance a (rate, channels) key runs on: keys that share it share ONE launch
+  // ("merge_launches" 1, default), and it is the launch that has to fill the GPU -- a plan of a few
+  // tracks at each of 48 / 96 / 192 kHz (C5) would otherwise be three short launches, each with its
+  // own partial last round.  The segments of a launch are sized to equal numbers of TILES (a
+  // sub-block is 1 tile at 48 kHz and C = 75, 4 at 192 kHz).
+  struct LK {
+    int chunk; unsigned k; int mode; unsigned rate, ch;  // (rate, ch: 0 when launches merge)
+    bool operator<(const LK &o) const {
+      return std::tie(chunk, k, mode, rate, ch) < std::tie(o.chunk, o.k, o.mode, o.rate, o.ch);
+    }
+  };
+  auto launch_key = [&](unsigned rate, unsigned ch, unsigned g_nch, bool first_group) -> LK {
+    const unsigned sw = strided_for(rate, ch);
+    const int tp_ = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(rate) : 0;
+    const int s100_ = (int)((rate + 5) / 10);
+    int chunk = sw ? pick_chunk(c->p_chunk, s100_, sw, tp_)
+                   : (((g_nch <= 6 || g_nch == 8) && g_nch == ch) ? pick_chunk(c->p_chunk, s100_, g_nch, tp_) : 0);
+    const int mode = sw ? 2 : (chunk ? 0 : 1);
+    if (!chunk) chunk = 25;
+    (void)first_group;
+    return LK{chunk, g_nch, mode, c->p_merge ? 0u : rate, c->p_merge ? 0u : ch};
+  };
+  struct ClassAcc { double tiles = 0.0, tps_min = 1e30; std::vector<RC> keys; };
+  std::map<LK, ClassAcc> classes;
   for (const auto &kv : key_sb) {
     const unsigned str = strided_for(kv.first.rate, kv.first.ch);
     const unsigned k = str ? str : std::min<unsigned>(kv.first.ch, LGD_GROUP_CH);
+    const LK lk = launch_key(kv.first.rate, kv.first.ch, k, true);
+    const double tps = (double)((kv.first.rate + 5) / 10) / (64.0 * lk.chunk);  // tiles per sub-block
+    ClassAcc &a = classes[lk];
+    a.tiles += (double)kv.second * tps;
+    a.tps_min = std::min(a.tps_min, tps);
+    a.keys.push_back(kv.first);
+  }
+  for (const auto &cl : classes) {
+    const unsigned k = cl.first.k;
     const unsigned per_cu = k <= 2 ? std::max(1u, (unsigned)c->p_waves_per_cu / k)
                                    : (k > 8 ? std::max(1u, 16u / k) : std::max(1u, 12u / k));
     const uint64_t slots = (uint64_t)c->n_cu * per_cu;
-    const uint64_t rounds = std::max<uint64_t>(1, (kv.second + slots * max_seg - 1) / (slots * max_seg));
-    uint64_t seg = (kv.second + rounds * slots - 1) / (rounds * slots);
-    if (c->p_seg_sb) seg = (uint64_t)c->p_seg_sb;
-    else seg = std::max(seg, min_seg);
-    key_seg[kv.first] = std::max<uint64_t>(1, seg);
+    for (const RC &key : cl.second.keys) {
+      uint64_t seg;
+      if (cl.second.keys.size() == 1) {
+        const uint64_t sb = key_sb[key];
+        const uint64_t rounds = std::max<uint64_t>(1, (sb + slots * max_seg - 1) / (slots * max_seg));
+        seg = (sb + rounds * slots - 1) / (rounds * slots);
+      } else {
+        // rounds: the key with the fewest tiles per sub-block gets segments of <= max_seg sub-blocks
+        const double per_round = (double)slots * (double)max_seg * cl.second.tps_min;
+        const double rounds = std::max(1.0, std::ceil(cl.second.tiles / per_round - 1e-9));
+        const double target = cl.second.tiles / (rounds * (double)slots);  // tiles per segment
+        const double tps = (double)((key.rate + 5) / 10) / (64.0 * cl.first.chunk);
+        seg = (uint64_t)std::max(1.0, std::ceil(target / tps - 1e-9));
+      }
+      if (c->p_seg_sb) seg = (uint64_t)c->p_seg_sb;
+      else seg = std::max(seg, min_seg);
+      key_seg[key] = std::max<uint64_t>(1, seg);
+    }
   }
+  std::map<LK, size_t> launch_of;
+  c->launches.clear();
 
   for (uint32_t t = 0; t < n; ++t) {
     const lgd_track &tr = tracks[t];
@@ -653,6 +712,22 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         g.F.pad = (int)c->p_debug;
         g.seg_begin = g.seg_count = 0;
         g.rows_max = 0;
+        {
+          LK lk = launch_key(tr.rate, tr.channels, g_nch, ch0 == 0);
+          // (the kernel instance is what the group itself settled on)
+          lk.chunk = g.chunk;
+          lk.mode = g.strided ? 2 : (g.generic ? 1 : 0);
+          auto li = launch_of.find(lk);
+          if (li == launch_of.end()) {
+            li = launch_of.emplace(lk, c->launches.size()).first;
+            c->launches.push_back(Launch{g.chunk, (int)g.nch, 0, lk.mode, 0, 0, {}});
+          }
+          g.launch = li->second;
+          Launch &L = c->launches[g.launch];
+          L.tp = L.tp || g.tp;
+          L.groups.push_back(c->groups.size());
+        }
+        if (c->groups.size() >= MAX_GROUPS) return fail(LGD_EUNSUP, "more than %zu (rate, channels) groups in one plan", MAX_GROUPS);
         it = group_of.emplace(key, c->groups.size()).first;
         c->groups.push_back(g);
         group_segs.emplace_back();
@@ -679,7 +754,8 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         sg.n_tiles = (int)((sg.f_peak_end - sg.f0 + tile_f - 1) / tile_f);
         sg.n_frames = (long long)tr.frames;
         sg.hint = (float *)(uintptr_t)m.hint_off;
-        sg.tp_rows = nullptr;
+        sg.filt = (const void *)(uintptr_t)it->second;  // group index, patched to its device constants
+        sg.tp_rows = (void *)~(uintptr_t)0;  // no interpolator: patched to null
         if (g.tp) {  // one row of candidate bits per tile and channel of this workgroup
           const long long n_tiles = sg.n_tiles;
           const long long rows = n_tiles * (long long)g_nch;
@@ -708,20 +784,33 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
           for (uint64_t sgi = base; sgi < std::min<uint64_t>(nseg, base + 8); ++sgi) out.push_back(pair_segs[pi][sgi]);
     }
   }
-  for (size_t gi = 0; gi < c->groups.size(); ++gi) {
-    c->groups[gi].seg_begin = c->segs.size();
-    c->groups[gi].seg_count = group_segs[gi].size();
-    c->segs.insert(c->segs.end(), group_segs[gi].begin(), group_segs[gi].end());
-  }
-  {  // launch order: most PCM bytes first
-    std::vector<double> bytes(c->groups.size(), 0.0);
+  {  // launch order: most PCM bytes first; inside a launch its groups' segments, longest first
+     // (each group contiguous: lgd_tp_kernel runs per group)
+    std::vector<double> bytes(c->launches.size(), 0.0);
+    std::vector<double> seg_tiles(c->groups.size(), 0.0);
     for (size_t gi = 0; gi < c->groups.size(); ++gi)
-      for (const LgdSeg &sg : group_segs[gi])
-        bytes[gi] += (double)(sg.f_peak_end - sg.f0) * c->groups[gi].nch;
-    c->group_order.resize(c->groups.size());
-    for (size_t gi = 0; gi < c->groups.size(); ++gi) c->group_order[gi] = gi;
-    std::stable_sort(c->group_order.begin(), c->group_order.end(),
-                     [&](size_t a, size_t b) { return bytes[a] > bytes[b]; });
+      for (const LgdSeg &sg : group_segs[gi]) {
+        bytes[c->groups[gi].launch] += (double)(sg.f_peak_end - sg.f0) * c->groups[gi].nch;
+        seg_tiles[gi] = std::max(seg_tiles[gi], (double)(sg.n_tiles + sg.n_warm_tiles));
+      }
+    std::vector<size_t> order(c->launches.size());
+    for (size_t li = 0; li < order.size(); ++li) order[li] = li;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bytes[a] > bytes[b]; });
+    std::vector<Launch> sorted;
+    for (size_t li : order) {
+      Launch L = c->launches[li];
+      std::stable_sort(L.groups.begin(), L.groups.end(), [&](size_t a, size_t b) { return seg_tiles[a] > seg_tiles[b]; });
+      L.seg_begin = c->segs.size();
+      for (size_t gi : L.groups) {
+        c->groups[gi].launch = sorted.size();
+        c->groups[gi].seg_begin = c->segs.size();
+        c->groups[gi].seg_count = group_segs[gi].size();
+        c->segs.insert(c->segs.end(), group_segs[gi].begin(), group_segs[gi].end());
+      }
+      L.seg_count = c->segs.size() - L.seg_begin;
+      sorted.push_back(L);
+    }
+    c->launches.swap(sorted);
   }
 
   HIPCHK(hipDeviceSynchronize());  // nothing of an older plan may still be running
@@ -778,8 +867,9 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
       sg.e_out = w.d_E + (uintptr_t)sg.e_out;
       sg.peak_out = w.d_peaks + (uintptr_t)sg.peak_out;
       sg.hint = w.d_hint + (uintptr_t)sg.hint;
-      // (sg.tp_rows holds an element offset; only interpolating groups use it)
-      sg.tp_rows = w.d_tp_rows + (uintptr_t)sg.tp_rows;
+      // (sg.tp_rows holds a byte offset; segments of a rate without interpolator get null)
+      sg.tp_rows = sg.tp_rows == (void *)~(uintptr_t)0 ? nullptr : (void *)(w.d_tp_rows + (uintptr_t)sg.tp_rows);
+      sg.filt = c->d_filt + (uintptr_t)sg.filt;
     }
     for (uint32_t t = 0; t < n; ++t) {
       c->ranges[t].off = c->meta[t].st_off;
@@ -955,19 +1045,17 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   // 2.88 ms instead of 2.65 ms for the scan kernels (kernels of different LDS footprints share
   // CUs badly, and every cross-stream dependency costs its latency), hence off by default; every
   // group is sized to fill the GPU by itself instead (see the segment lengths in lgd_plan).
-  const size_t ng = c->groups.size();
+  const size_t ng = c->launches.size();
   const int n_side = (c->p_group_streams && ng > 1) ? (int)std::min<size_t>(ng - 1, lgd_ctx::GSTREAMS) : 0;
   if (n_side) {
     HIPCHK(hipEventRecord(c->ev_fork, s));
     for (int i = 0; i < n_side; ++i) HIPCHK(hipStreamWaitEvent(c->gstream[i], c->ev_fork, 0));
   }
   for (size_t k = 0; k < ng; ++k) {
-    const size_t gi = c->group_order[k];
-    const Group &g = c->groups[gi];
+    const Launch &L = c->launches[k];
     const int lane = n_side ? (int)(k % (size_t)(n_side + 1)) : 0;
     hipStream_t gs = lane == 0 ? s : c->gstream[lane - 1];
-    HIPCHK(lgd_launch_scan(g.chunk, (int)g.nch, g.tp, g.strided ? 2 : (g.generic ? 1 : 0), w.d_segs + g.seg_begin,
-                           (int)g.seg_count, c->d_filt + gi, gs));
+    HIPCHK(lgd_launch_scan(L.chunk, L.nch, L.tp ? 4 : 0, L.mode, w.d_segs + L.seg_begin, (int)L.seg_count, gs));
   }
   for (int i = 0; i < n_side; ++i) {
     HIPCHK(hipEventRecord(c->ev_gjoin[i], c->gstream[i]));
@@ -978,6 +1066,10 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   // can exceed them
   if (c->flags & LGD_FLAG_TRUE_PEAK)
     HIPCHK(lgd_launch_peak_reduce(c->d_meta, n, w.d_peaks, w.d_hint, s));
+  // One true-peak launch per interpolating group (the kernel's index arithmetic is per chunk length,
+  // channel count and interpolation factor).  (Sending the launches of a mixed plan out on four
+  // streams at once was measured on C5: 2.563 -> 2.546 ms of kernel time, but the event packets
+  // cost the pipelined step 2.40 -> 2.62 ms: not done.)
   for (size_t gi = 0; gi < c->groups.size(); ++gi) {
     const Group &g = c->groups[gi];
     HIPCHK(lgd_launch_tp(g.chunk, (int)g.nch, g.tp, w.d_segs + g.seg_begin, (int)g.seg_count, g.rows_max,

@@ -27,6 +27,8 @@ struct LgdSeg {
                          // n tiles fills the top n slots); null without interpolator
   float *hint;           // [nch_total] this track's per-channel sample peak (lgd_peak_reduce_kernel): the
                          // bound lgd_tp_kernel prunes with
+  const void *filt;      // the LgdFilt of this segment's (rate, chunk) in device memory: per segment, so that
+                         // one scan launch can carry the segments of several sample rates
 };
 
 // Per-(rate, chunk) constants, passed by value as a kernel argument.

@@ -188,7 +188,7 @@ template <int C, int G, int TP, bool WIDE = false, bool STR = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
                                                       G ? LGD_WAVE * G : (WIDE ? 1024 : 512)),
                           amdgpu_waves_per_eu(G ? (G > 2 ? 3 : 2) : (WIDE ? 4 : 2), 4))) void lgd_scan_kernel(
-    const LgdSeg *__restrict__ segs, const LgdFilt *__restrict__ Fg, const int nch_rt) {
+    const LgdSeg *__restrict__ segs, const int nch_rt) {
   using K = ScanCfg<C, TP>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -196,7 +196,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // this address space are scalar loads (s_load), so the 72 doubles of scan
   // matrices are fetched per tile instead of occupying (and spilling) SGPRs
   typedef const LgdFilt __attribute__((address_space(4))) *cfilt_ptr;
-  const cfilt_ptr F0 = (cfilt_ptr)Fg;
 #define F (*F0)
   const int nch = G ? G : nch_rt;          // channels == waves in this workgroup
   const int tid = threadIdx.x;
@@ -205,6 +204,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   const int ch = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = LGD_WAVE * nch;
   const LgdSeg sg = segs[blockIdx.x];
+  // the constants of this segment's (rate, chunk): per segment, so that one launch can carry the
+  // segments of several sample rates
+  const cfilt_ptr F0 = (cfilt_ptr)sg.filt;
   static_assert(!STR || G == 1 || G == 2 || G == 3, "strided variant: one to three channels per workgroup");
   const int shift = (STR || (G == 0 && sg.nch_total != (G ? G : nch_rt))) ? 0 : (int)((sg.f0 * nch) & 3);
   const long long n_frames = sg.n_frames;
@@ -420,7 +422,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     if constexpr (TP != 0) {
       // (behind the loads just issued, and only one store per LGD_ROW_TILES tiles: a vector store
       // costs the wave ~0.4 us here whatever its width -- one per tile was 10 % of the kernel)
-      if (k > 0 && (k & (LGD_ROW_TILES - 1)) == 0) {
+      // (a launch may carry segments of a rate without interpolator -- 192 kHz: tp_rows is null)
+      if (k > 0 && (k & (LGD_ROW_TILES - 1)) == 0 && sg.tp_rows != nullptr) {
         *row_p = mc_rows;
         row_p += nch * LGD_WAVE;
       }
@@ -696,7 +699,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   }
 
   if constexpr (TP != 0) {
-    if (n_main > 0) *row_p = mc_rows;  // the last group: n_main mod 8 tiles (8 if 0), newest on top
+    if (n_main > 0 && sg.tp_rows != nullptr) *row_p = mc_rows;  // the last group: n_main mod 8 tiles (8 if 0), newest on top
   }
   {
     const float s = wave_max_f32(pk_s);
@@ -984,7 +987,7 @@ extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
 __global__ void lgd_prime_kernel() {}
 
 template <int C, int G, int TP, bool WIDE = false, bool STR = false>
-static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, const LgdFilt *F, int nch,
+static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, int nch,
                                 hipStream_t s) {
   const size_t lds_bytes = lgd_scan_lds_bytes(C, nch, TP, G == 0);
   if constexpr (G == 1 || G == 3) hipLaunchKernelGGL(lgd_prime_kernel, dim3(1024), dim3(LGD_WAVE), 0, s);
@@ -994,64 +997,64 @@ static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, const LgdFilt *F,
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((lgd_scan_kernel<C, G, TP, WIDE, STR>), dim3(n_seg), dim3(LGD_WAVE * nch), lds_bytes, s,
-                     segs, F, nch);
+                     segs, nch);
   return hipGetLastError();
 }
 
 // channel pairs (or single channels) of a wider interleaved stream
 template <int C>
-static hipError_t launch_scan_strided(int nch, int tp, const LgdSeg *segs, int n_seg, const LgdFilt *F,
+static hipError_t launch_scan_strided(int nch, int tp, const LgdSeg *segs, int n_seg,
                                       hipStream_t s) {
   if (nch == 1) {
-    if (tp) return launch_scan_t<C, 1, 4, false, true>(segs, n_seg, F, nch, s);
-    return launch_scan_t<C, 1, 0, false, true>(segs, n_seg, F, nch, s);
+    if (tp) return launch_scan_t<C, 1, 4, false, true>(segs, n_seg, nch, s);
+    return launch_scan_t<C, 1, 0, false, true>(segs, n_seg, nch, s);
   }
   if (nch == 3) {
     if constexpr (C <= 50) {  // (three planes: the chunk lengths the three-channel kernel is built for)
-      if (tp) return launch_scan_t<C, 3, 4, false, true>(segs, n_seg, F, nch, s);
-      return launch_scan_t<C, 3, 0, false, true>(segs, n_seg, F, nch, s);
+      if (tp) return launch_scan_t<C, 3, 4, false, true>(segs, n_seg, nch, s);
+      return launch_scan_t<C, 3, 0, false, true>(segs, n_seg, nch, s);
     }
     return hipErrorInvalidValue;
   }
   if (nch != 2) return hipErrorInvalidValue;
-  if (tp) return launch_scan_t<C, 2, 4, false, true>(segs, n_seg, F, nch, s);
-  return launch_scan_t<C, 2, 0, false, true>(segs, n_seg, F, nch, s);
+  if (tp) return launch_scan_t<C, 2, 4, false, true>(segs, n_seg, nch, s);
+  return launch_scan_t<C, 2, 0, false, true>(segs, n_seg, nch, s);
 }
 
 // the generic kernel (any channel count, channel groups, any sub-block alignment)
 // exists for the shortest chunk only
 #define LGD_GENERIC_CHUNK 25
 template <int TP>
-static hipError_t launch_scan_generic(int nch, const LgdSeg *segs, int n_seg, const LgdFilt *F,
+static hipError_t launch_scan_generic(int nch, const LgdSeg *segs, int n_seg,
                                       hipStream_t s) {
-  if (nch <= 8) return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, false>(segs, n_seg, F, nch, s);
-  return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, true>(segs, n_seg, F, nch, s);
+  if (nch <= 8) return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, false>(segs, n_seg, nch, s);
+  return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, true>(segs, n_seg, nch, s);
 }
 
 template <int C>
-static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg, const LgdFilt *F,
+static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg,
                                 hipStream_t s) {
   if (nch == 1) {
-    if (tp == 4) return launch_scan_t<C, 1, 4>(segs, n_seg, F, nch, s);
-    if (tp == 2) return launch_scan_t<C, 1, 4>(segs, n_seg, F, nch, s);
-    return launch_scan_t<C, 1, 0>(segs, n_seg, F, nch, s);
+    if (tp == 4) return launch_scan_t<C, 1, 4>(segs, n_seg, nch, s);
+    if (tp == 2) return launch_scan_t<C, 1, 4>(segs, n_seg, nch, s);
+    return launch_scan_t<C, 1, 0>(segs, n_seg, nch, s);
   }
   if (nch > 2) {  // 3 .. 6 or 8 planes per workgroup (2.1, quad, 5.0, 5.1, 7.1): the short chunks only
     if constexpr (C <= 50) {
 #define LGD_DISPATCH_G(g_)                                                              \
       if (nch == g_) {                                                                  \
-        if (tp == 4) return launch_scan_t<C, g_, 4>(segs, n_seg, F, nch, s);            \
-        if (tp == 2) return launch_scan_t<C, g_, 4>(segs, n_seg, F, nch, s);            \
-        return launch_scan_t<C, g_, 0>(segs, n_seg, F, nch, s);                         \
+        if (tp == 4) return launch_scan_t<C, g_, 4>(segs, n_seg, nch, s);            \
+        if (tp == 2) return launch_scan_t<C, g_, 4>(segs, n_seg, nch, s);            \
+        return launch_scan_t<C, g_, 0>(segs, n_seg, nch, s);                         \
       }
       LGD_DISPATCH_G(3) LGD_DISPATCH_G(4) LGD_DISPATCH_G(5) LGD_DISPATCH_G(6) LGD_DISPATCH_G(8)
 #undef LGD_DISPATCH_G
     }
     return hipErrorInvalidValue;
   }
-  if (tp == 4) return launch_scan_t<C, 2, 4>(segs, n_seg, F, nch, s);
-  if (tp == 2) return launch_scan_t<C, 2, 4>(segs, n_seg, F, nch, s);
-  return launch_scan_t<C, 2, 0>(segs, n_seg, F, nch, s);
+  if (tp == 4) return launch_scan_t<C, 2, 4>(segs, n_seg, nch, s);
+  if (tp == 2) return launch_scan_t<C, 2, 4>(segs, n_seg, nch, s);
+  return launch_scan_t<C, 2, 0>(segs, n_seg, nch, s);
 }
 
 // rows_max: most rows (tiles x channels) any segment of the launch has
@@ -1090,36 +1093,36 @@ extern "C" const int lgd_chunk_table[] = {25, 35, 45, 49, 50, 63, 75, 0};
 // generic: 0 = planar kernel of `nch` channels, 1 = run-time-channel kernel, 2 = channel pair /
 // single channel (nch = 2 / 1) of a wider interleaved stream
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, const LgdSeg *segs,
-                                      int n_seg, const LgdFilt *F, hipStream_t s) {
+                                      int n_seg, hipStream_t s) {
   if (n_seg <= 0) return hipSuccess;
   if (generic == 2) {
     switch (chunk) {
-      case 25: return launch_scan_strided<25>(nch, tp, segs, n_seg, F, s);
-      case 35: return launch_scan_strided<35>(nch, tp, segs, n_seg, F, s);
-      case 45: return launch_scan_strided<45>(nch, tp, segs, n_seg, F, s);
-      case 49: return launch_scan_strided<49>(nch, tp, segs, n_seg, F, s);
-      case 50: return launch_scan_strided<50>(nch, tp, segs, n_seg, F, s);
-      case 63: return launch_scan_strided<63>(nch, tp, segs, n_seg, F, s);
-      case 75: return launch_scan_strided<75>(nch, tp, segs, n_seg, F, s);
+      case 25: return launch_scan_strided<25>(nch, tp, segs, n_seg, s);
+      case 35: return launch_scan_strided<35>(nch, tp, segs, n_seg, s);
+      case 45: return launch_scan_strided<45>(nch, tp, segs, n_seg, s);
+      case 49: return launch_scan_strided<49>(nch, tp, segs, n_seg, s);
+      case 50: return launch_scan_strided<50>(nch, tp, segs, n_seg, s);
+      case 63: return launch_scan_strided<63>(nch, tp, segs, n_seg, s);
+      case 75: return launch_scan_strided<75>(nch, tp, segs, n_seg, s);
       default: return hipErrorInvalidValue;
     }
   }
   if (nch < 1 || nch > 16) return hipErrorInvalidValue;
   if (generic) {
     if (chunk != LGD_GENERIC_CHUNK) return hipErrorInvalidValue;
-    if (tp == 4) return launch_scan_generic<4>(nch, segs, n_seg, F, s);
-    if (tp == 2) return launch_scan_generic<4>(nch, segs, n_seg, F, s);
-    return launch_scan_generic<0>(nch, segs, n_seg, F, s);
+    if (tp == 4) return launch_scan_generic<4>(nch, segs, n_seg, s);
+    if (tp == 2) return launch_scan_generic<4>(nch, segs, n_seg, s);
+    return launch_scan_generic<0>(nch, segs, n_seg, s);
   }
   if (nch > 8 || nch == 7) return hipErrorInvalidValue;
   switch (chunk) {
-    case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, F, s);
-    case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, F, s);
-    case 45: return launch_scan_c<45>(nch, tp, segs, n_seg, F, s);
-    case 49: return launch_scan_c<49>(nch, tp, segs, n_seg, F, s);
-    case 50: return launch_scan_c<50>(nch, tp, segs, n_seg, F, s);
-    case 63: return launch_scan_c<63>(nch, tp, segs, n_seg, F, s);
-    case 75: return launch_scan_c<75>(nch, tp, segs, n_seg, F, s);
+    case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, s);
+    case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, s);
+    case 45: return launch_scan_c<45>(nch, tp, segs, n_seg, s);
+    case 49: return launch_scan_c<49>(nch, tp, segs, n_seg, s);
+    case 50: return launch_scan_c<50>(nch, tp, segs, n_seg, s);
+    case 63: return launch_scan_c<63>(nch, tp, segs, n_seg, s);
+    case 75: return launch_scan_c<75>(nch, tp, segs, n_seg, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -580,3 +580,36 @@ def test_channel_triple_workgroups(oracle, rate, nch):
     np.testing.assert_allclose(ea, eb, rtol=energy_rtol(rate))
     assert np.array_equal(spa, spb) and np.array_equal(tpa, tpb)
     assert (a["n_abs"], a["n_rel"], a["n_st"]) == (b["n_abs"], b["n_rel"], b["n_st"])
+
+
+def test_merged_launches_of_a_mixed_plan(oracle):
+    """"merge_launches" 1 (default): the (rate, channels) groups of a plan that run the same kernel instance
+    -- 48 / 96 / 192 kHz stereo at C = 75, the 5.1 triples at C = 50 ... -- go out as ONE launch, constants per
+    segment, 192 kHz segments (no interpolator) beside interpolating ones.  Same results as one launch per
+    group ("merge_launches" 0), track by track, and both equal the oracle."""
+    from loudgain_amd.device import DeviceScanner
+    layout = [(48000, 2, 7.3), (96000, 2, 5.1), (192000, 2, 3.7), (44100, 2, 6.9), (48000, 1, 9.1), (192000, 1, 4.3),
+              (96000, 1, 6.1), (48000, 6, 4.9), (96000, 6, 3.1), (192000, 6, 2.3), (44100, 6, 3.3), (48000, 2, 0.35),
+              (32000, 2, 5.5), (22050, 1, 8.1), (11025, 2, 6.0), (48000, 3, 4.1), (96000, 3, 2.9)]
+    pcms, rates = [], []
+    for i, (rate, nch, secs) in enumerate(layout):
+        pcms.append(synth.track_numpy(int(rate * secs) + 7 * i, nch, rate, seed=900 + i, step_s=0.9))
+        rates.append(rate)
+    devs = [to_dev(p) for p in pcms]
+    out = []
+    for merge in (1, 0):
+        sc = DeviceScanner(0)
+        sc.set_param("merge_launches", merge)
+        res, _ = sc.scan(devs, rates)
+        peaks = [sc.channel_peaks(i, p.shape[1]) for i, p in enumerate(pcms)]
+        energies = [sc.subblock_energies(i) for i in range(len(pcms))]
+        out.append((res, peaks, energies, sc.plan_info()["segments"]))
+        sc.close()
+    (ra, pa, ea, na), (rb, pb, eb, nb) = out
+    assert na != nb                      # the two plans really are cut differently
+    for i, (p, rate) in enumerate(zip(pcms, rates)):
+        check_track(ra[i], oracle.scan_track(p, rate), rate=rate)
+        for k in ("loudness", "lra", "peak", "true_peak", "sample_peak", "n_abs", "n_rel", "n_st"):
+            assert ra[i][k] == rb[i][k] or (ra[i][k] != ra[i][k] and rb[i][k] != rb[i][k]), (i, k)
+        assert np.array_equal(pa[i][0], pb[i][0]) and np.array_equal(pa[i][1], pb[i][1])
+        assert np.array_equal(ea[i], eb[i])      # sub-block energies do not depend on the segmentation
