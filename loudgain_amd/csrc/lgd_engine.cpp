@@ -602,7 +602,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
       return std::tie(chunk, k, mode, rate, ch) < std::tie(o.chunk, o.k, o.mode, o.rate, o.ch);
     }
   };
-  auto launch_key = [&](unsigned rate, unsigned ch, unsigned g_nch, bool first_group) -> LK {
+  auto launch_key = [&](unsigned rate, unsigned ch, unsigned g_nch) -> LK {
     const unsigned sw = strided_for(rate, ch);
     const int tp_ = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(rate) : 0;
     const int s100_ = (int)((rate + 5) / 10);
@@ -610,7 +610,6 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
                    : (((g_nch <= 6 || g_nch == 8) && g_nch == ch) ? pick_chunk(c->p_chunk, s100_, g_nch, tp_) : 0);
     const int mode = sw ? 2 : (chunk ? 0 : 1);
     if (!chunk) chunk = 25;
-    (void)first_group;
     return LK{chunk, g_nch, mode, c->p_merge ? 0u : rate, c->p_merge ? 0u : ch};
   };
   struct ClassAcc { double tiles = 0.0, tps_min = 1e30; std::vector<RC> keys; };
@@ -618,7 +617,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   for (const auto &kv : key_sb) {
     const unsigned str = strided_for(kv.first.rate, kv.first.ch);
     const unsigned k = str ? str : std::min<unsigned>(kv.first.ch, LGD_GROUP_CH);
-    const LK lk = launch_key(kv.first.rate, kv.first.ch, k, true);
+    const LK lk = launch_key(kv.first.rate, kv.first.ch, k);
     const double tps = (double)((kv.first.rate + 5) / 10) / (64.0 * lk.chunk);  // tiles per sub-block
     ClassAcc &a = classes[lk];
     a.tiles += (double)kv.second * tps;
@@ -713,7 +712,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         g.seg_begin = g.seg_count = 0;
         g.rows_max = 0;
         {
-          LK lk = launch_key(tr.rate, tr.channels, g_nch, ch0 == 0);
+          LK lk = launch_key(tr.rate, tr.channels, g_nch);
           // (the kernel instance is what the group itself settled on)
           lk.chunk = g.chunk;
           lk.mode = g.strided ? 2 : (g.generic ? 1 : 0);

@@ -18,5 +18,6 @@ bash tools/prof1.sh ${TAG}_c2_pipelined --workload c2 > gpurun_out/${TAG}_prof_c
 bash tools/pmc.sh ${TAG}_c2 --workload c2 --serial > gpurun_out/${TAG}_pmc_c2.log 2>&1
 bash tools/pmc.sh ${TAG}_c3 --workload c3 --serial > gpurun_out/${TAG}_pmc_c3.log 2>&1
 timeout -k 10 900 python tools/rate_sweep.py > gpurun_out/${TAG}_rate_sweep.txt 2>/dev/null
+timeout -k 10 600 python tools/library_bench.py --albums 40 > gpurun_out/${TAG}_library_bench.json 2> gpurun_out/${TAG}_library_bench.err; echo "library rc=$?"
 for f in default c3 c4 c5; do cut -c1-400 gpurun_out/${TAG}_bench_$f.json; echo; done
 for w in c2 c3 c4 c5; do head -5 gpurun_out/prof_${TAG}_$w/kernel_stats.csv | cut -c1-160; done
