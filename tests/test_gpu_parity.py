@@ -612,3 +612,25 @@ def test_merged_launches_of_a_mixed_plan(oracle):
             assert ra[i][k] == rb[i][k] or (ra[i][k] != ra[i][k] and rb[i][k] != rb[i][k]), (i, k)
         assert np.array_equal(pa[i][0], pb[i][0]) and np.array_equal(pa[i][1], pb[i][1])
         assert np.array_equal(ea[i], eb[i])      # sub-block energies do not depend on the segmentation
+
+
+def test_non_finite_samples_stay_in_their_track(oracle):
+    """The reference never sees NaN / Inf (scan.c:414 resamples everything to S16), the f32 entry point can:
+    such a track's own numbers are unspecified, but the scan must return and the other tracks of the plan
+    must come out exactly as they do alone."""
+    from loudgain_amd.device import DeviceScanner
+    rate = 48000
+    good = [synth.track_numpy(rate * 11 + 5, 2, rate, seed=41, step_s=1.1), synth.track_numpy(rate * 7, 2, rate, seed=42, step_s=0.8)]
+    bad = synth.track_numpy(rate * 9, 2, rate, seed=43, step_s=1.0).copy()
+    bad[rate * 2 + 17, 0] = np.nan
+    bad[rate * 5 + 3, 1] = np.inf
+    bad[rate * 6 + 1, 0] = -np.inf
+    sc = DeviceScanner(0)
+    res, _ = sc.scan([to_dev(good[0]), to_dev(bad), to_dev(good[1])], rate)
+    solo = [sc.scan([to_dev(g)], rate)[0][0] for g in good]
+    sc.close()
+    for got, want, pcm in ((res[0], solo[0], good[0]), (res[2], solo[1], good[1])):
+        for k in ("loudness", "lra", "peak", "true_peak", "sample_peak", "n_abs", "n_rel", "n_st"):
+            assert got[k] == want[k], k
+        check_track(got, oracle.scan_track(pcm, rate))
+    assert res[1]["n_blocks"] == 87       # 9 s: the block grid does not depend on the samples
