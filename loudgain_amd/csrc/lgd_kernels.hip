@@ -805,6 +805,10 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
   // evaluated.  The result is bit-identical to evaluating everything (tp_prune 0: thr < 0).
   float thr = -1.f;
   if (F0->tp_prune) thr = ((const float LGD_GLOBAL *)sg.hint)[chan] * F0->tp_thr;
+  // A whole segment whose sample peak (exact, written by the scan kernel) stays at or below the
+  // threshold has no chunk that can matter -- except the first of its first tile, whose history
+  // lies in front of the segment: rows of later tiles leave before reading their record.
+  if (k > 0 && !(((const float LGD_GLOBAL *)sg.peak_out)[chan] > thr)) return;
   // Which chunks can matter: the interpolator outputs of lane l's chunk read its own frames and
   // the last HX of the chunk before it, so they are bounded by L1 * max(mc[l], mc[l - 1]) (mc =
   // the chunk maxima the scan kernel stored; the chunk before lane 0 is lane 63 of the previous
