@@ -1296,3 +1296,15 @@ extern "C" int lgd_plan_info(lgd_ctx *c, uint64_t *n_segments, uint64_t *n_subbl
   if (warm_bytes) *warm_bytes = c->warm_bytes;
   return LGD_OK;
 }
+
+#ifdef LGD_DEBUG_HWID
+// placement probe build only: the chunk-maxima rows of the last scan (the scan kernel left its
+// per-wave HW_ID records in them)
+extern "C" int lgd_debug_rows(lgd_ctx *c, void *dst, size_t bytes) {
+  if (!c || !c->executed) return -1;
+  (void)hipDeviceSynchronize();
+  lgd_ctx::WorkSet &w = c->ws[c->cur_set];
+  return (int)hipMemcpy(dst, w.d_tp_rows, bytes, hipMemcpyDeviceToHost);
+}
+#endif
+

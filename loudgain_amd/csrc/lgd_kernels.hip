@@ -256,6 +256,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   u32x4 LGD_GLOBAL *row_p = (u32x4 LGD_GLOBAL *)sg.tp_rows + (ch * LGD_WAVE + lane);
 
   const int n_main = sg.n_tiles;
+#ifdef LGD_DEBUG_HWID
+  // placement probe (make libloudscan_hip_hwid.so, tools/hwid_probe.py): where this wave runs, when
+  const unsigned dbg_hw = __builtin_amdgcn_s_getreg(63492 /* HW_ID */), dbg_xcc = __builtin_amdgcn_s_getreg(63508 /* XCC_ID */);
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- tile staging: coalesced 16-B loads -> registers -> LDS.  The NEXT tile's
   // loads are issued before the current tile is computed (software prefetch,
@@ -701,6 +706,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   if constexpr (TP != 0) {
     if (n_main > 0 && sg.tp_rows != nullptr) *row_p = mc_rows;  // the last group: n_main mod 8 tiles (8 if 0), newest on top
   }
+#ifdef LGD_DEBUG_HWID
+  if constexpr (TP != 0) {  // the wave's record replaces the first 16 bytes of its channel's first row
+    const unsigned long long dbg_t1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (lane == 0 && sg.tp_rows != nullptr)
+      ((u32x4 LGD_GLOBAL *)sg.tp_rows)[ch] = (u32x4){dbg_hw, dbg_xcc, (unsigned)dbg_t0, (unsigned)dbg_t1};
+  }
+#endif
   {
     const float s = wave_max_f32(pk_s);
     if (lane == 0) {

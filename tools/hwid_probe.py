@@ -1,5 +1,8 @@
-"""Where do the mono scan kernel's one-wave workgroups land?  (debug build lib_HWID.so: every
-workgroup leaves HW_ID, XCC_ID and its start / end time in its first chunk-maxima row.)"""
+"""Where do the scan kernel's waves land?  Needs the placement-probe build, in which every wave leaves HW_ID,
+XCC_ID and its start / end time in its channel's first chunk-maxima row:
+    make -C loudgain_amd/csrc libloudscan_hip_hwid.so
+    LOUDSCAN_LIB=$PWD/loudgain_amd/csrc/libloudscan_hip_hwid.so PROBE_CH=1 python tools/hwid_probe.py
+Prints waves per SIMD, workgroups per CU, start skew and wave duration by SIMD load (wave placement)."""
 import os, sys, ctypes, collections
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
