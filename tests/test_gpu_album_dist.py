@@ -30,7 +30,8 @@ def _tracks(kind="mixed"):
     if kind == "many":
         return _many_tracks()
     from loudgain_amd import synth
-    if kind == "long":   # > 8192 listed 3 s blocks in the gathered album list: the multi-workgroup LRA kernels
+    if kind in ("long", "long1"):   # > 8192 listed 3 s blocks in the gathered album list: the multi-workgroup LRA kernels
+        # ("long1": with scratch sized for ONE rank -- "album_world" 1 -- on two: the single-workgroup streaming select)
         return [(synth.track_numpy(8000 * 60 * 31, 1, 8000, seed=40 + i, step_s=13.0 + i), 8000) for i in range(6)]
     specs = [(48000, 2, 14.0, 1, 1.0), (48000, 2, 9.0, 2, 0.04), (44100, 1, 11.0, 3, 1.0),
              (48000, 2, 6.5, 4, 0.5), (96000, 2, 5.0, 5, 1.0), (48000, 6, 4.5, 6, 0.8), (48000, 2, 0.2, 7, 1.0)]
@@ -57,7 +58,10 @@ def _worker(rank, world, port, q, backend="gloo", kind="mixed"):
     tracks = _tracks(kind)
     mine = shard_indices(len(tracks), rank, world)
     dev = [torch.from_numpy(tracks[i][0]).cuda() for i in mine]
-    job = DistributedAlbumScanner(DeviceScanner(0), dev, [tracks[i][1] for i in mine],
+    sc = DeviceScanner(0)
+    if kind == "long1":
+        sc.set_param("album_world", 1)
+    job = DistributedAlbumScanner(sc, dev, [tracks[i][1] for i in mine],
                                   always_exchange=(backend == "nccl"))
     stream = torch.cuda.Stream()
     # five pipelined scans (both workspaces, scan k+1 under the exchange of scan k): the
@@ -70,7 +74,7 @@ def _worker(rank, world, port, q, backend="gloo", kind="mixed"):
 
 
 @pytest.mark.parametrize("world,backend,kind", [(1, "gloo", "mixed"), (2, "gloo", "mixed"), (3, "gloo", "mixed"),
-                                                (1, "nccl", "mixed"), (3, "gloo", "many"), (2, "gloo", "long")])
+                                                (1, "nccl", "mixed"), (3, "gloo", "many"), (2, "gloo", "long"), (2, "gloo", "long1")])
 def test_sharded_album_matches_oracle(oracle, world, backend, kind):
     """(1, "nccl"): the RCCL calls themselves (all-reduce SUM/MAX on engine-owned HBM,
     all-gather into a tensor) with one rank, where every collective is an identity."""
@@ -78,7 +82,7 @@ def test_sharded_album_matches_oracle(oracle, world, backend, kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 2000) + world + (7 if backend == "nccl" else 0) + (13 if kind == "many" else 0) \
-        + (29 if kind == "long" else 0)
+        + (29 if kind == "long" else 0) + (41 if kind == "long1" else 0)
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, kind)) for r in range(world)]
     for p in procs:
         p.start()

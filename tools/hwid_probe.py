@@ -20,14 +20,17 @@ sc.fetch()
 ks = sc.kernel_ms_stats(20)
 lib = _lib.load()
 info = sc.plan_info()
-n_seg = int(info["segments"]); seg_sb = -(-int(info["subblocks"]) // n_seg)
-tiles = seg_sb * (rate // 10) // (64 * int(info["chunk"]))
-per = -(-tiles // 8) * 1024 * ch
+n_seg = int(info["segments"])
+wg_ch = int(os.environ.get("PROBE_WG_CH", 3 if ch == 6 else (2 if ch in (5, 7) or ch > 16 else ch)))  # waves per workgroup (5.1: triples)
+n_sets = -(-ch // wg_ch) if wg_ch != ch else 1   # workgroup sets per segment (pairs / triples of a wider stream)
+seg_sb = -(-int(info["subblocks"]) * n_sets // n_seg)
+tiles = -(-seg_sb * (rate // 10) // (64 * int(info["chunk"])))
+per = -(-tiles // 8) * 1024 * wg_ch
 print("segments", n_seg, "sub-blocks each", seg_sb, "chunk", info["chunk"], "tiles", tiles)
 buf = np.zeros(n_seg * per // 4, np.uint32)
 lib.lgd_debug_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
 rc = lib.lgd_debug_rows(sc.ctx, buf.ctypes.data, buf.nbytes)
-d = buf.reshape(n_seg, per // 4)[:, :4 * ch].reshape(n_seg * ch, 4)
+d = buf.reshape(n_seg, per // 4)[:, :4 * wg_ch].reshape(n_seg * wg_ch, 4)
 hw, xcc, t0, t1 = d[:, 0], d[:, 1] & 15, d[:, 2].astype(np.int64), d[:, 3].astype(np.int64)
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 print("skip_tp", bool(os.environ.get("LGD_SKIP_TP")), "scan_only", round(ks["scan_only_mean_ms"], 4), "rc", rc)
