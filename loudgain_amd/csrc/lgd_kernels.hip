@@ -254,13 +254,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // where this lane's next record goes: [group of 8 tiles][channel][lane] (a per-lane pointer in
   // VGPRs: the scalar form kept the base and the group index live in SGPRs through the tile loop)
   u32x4 LGD_GLOBAL *row_p = (u32x4 LGD_GLOBAL *)sg.tp_rows + (ch * LGD_WAVE + lane);
-  // Mono / stereo workgroups have registers to spare: the records of the first LGD_ROW_PARK groups
+  // Mono / stereo / channel-triple / 7.1 workgroups have registers to spare (the planar three- and four-plane
+  // kernels at C = 50 do not: 168 VGPRs at three waves per SIMD): the records of the first LGD_ROW_PARK groups
   // (40 tiles) wait in registers and go out behind the tile loop, so that a segment of up to 48
   // tiles (C2 / C3: 36, C4: 48) stores nothing while it runs.  (A store inside the loop is
   // retired in order with the next tile's prefetch loads: when its acknowledgement is late the
   // wave waits for it.  Measured run to run, the true-peak variant of the stereo kernel was 0 to
-  // 6 % slower than the plain one with one store per 8 tiles.)
-  constexpr int LGD_ROW_PARK = (TP != 0 && G >= 1 && G <= 2) ? 5 : 0;
+  // 6 % slower than the plain one with one store per 8 tiles; 5.1 as triples with true peak 0.388 ->
+  // 0.367 ms, 7.1 0.399 -> 0.393 ms for 345.6 M samples.)
+  constexpr int LGD_ROW_PARK = (TP != 0 && ((G >= 1 && G <= 2) || (G == 3 && STR) || G == 8)) ? 5 : 0;
   u32x4 parked[LGD_ROW_PARK + 1];
 #pragma unroll
   for (int i = 0; i < LGD_ROW_PARK; ++i) parked[i] = (u32x4)(0u);
