@@ -113,7 +113,7 @@ const char *lgd_last_error(void);
  * sample peak -- exact, default; 0 = everywhere: the reference mode of the pruning tests),
  * "album_world" (ranks the scratch of the multi-GPU album's loudness range is sized for, default 8),
  * "strided" (3+ channel streams as one workgroup per channel pair or triple of every segment: 0 never,
- * 1 where measured faster = pairs for 5 / 7 / 17+ channels, triples for 5.1, default; 2 pairs always;
+ * 1 where measured faster = pairs for 5 / 7 / 17+ channels, triples for 5.1 (and for 3 channels with true peak), default; 2 pairs always;
  * 3 triples wherever the channel count divides by three), "merge_launches" (1, default: the (rate, channels) groups of a plan that run the same kernel
  * instance -- e.g. its 48, 96 and 192 kHz stereo tracks -- are scanned by one launch, sized to fill the GPU
  * together; 0: one launch per group), "group_streams" (1 = the groups of a

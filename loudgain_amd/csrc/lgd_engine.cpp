@@ -580,7 +580,10 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if (!c->p_strided || ch < 3) return 0;
     const int tp_ = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(rate) : 0;
     const int s100_ = (int)((rate + 5) / 10);
-    if ((c->p_strided == 3 ? ch % 3 == 0 : (c->p_strided == 1 && ch == 6)) && pick_chunk(c->p_chunk, s100_, 3, tp_) != 0)
+    // (three channels: the one-triple form only with an interpolator -- 0.316 against 0.329 ms, where its chunk-maxima
+    // records can wait in registers; without, the planar kernel is 1 % ahead)
+    if ((c->p_strided == 3 ? ch % 3 == 0 : (c->p_strided == 1 && (ch == 6 || (ch == 3 && tp_)))) &&
+        pick_chunk(c->p_chunk, s100_, 3, tp_) != 0)
       return 3;
     if (c->p_strided != 2 && !(ch == 5 || ch == 7 || ch > LGD_GROUP_CH)) return 0;
     return pick_chunk(c->p_chunk, s100_, 2, tp_) != 0 ? 2 : 0;
