@@ -348,6 +348,19 @@ def traffic_from_profiles(tag):
         return None
 
 
+def valu_bound_from_profiles(tag):
+    """the VALU issue bound beside the HBM one.  Wave-instructions per launch from the committed
+    PMC pass (SQ_INSTS_VALU), priced at one instruction per 4 cycles and SIMD, 1024 SIMDs, 2.4 GHz."""
+    p = os.path.join(ROOT, "profiles", "traffic_%s.json" % tag)
+    try:
+        n = json.load(open(p)).get("valu_wave_instructions_per_launch")
+        return None if not n else {"wave_instructions_per_launch": n,
+                                   "ms_at_2400MHz": round(n / (1024 * 0.6e9) * 1e3, 4),
+                                   "source": "profiles/traffic_%s.json (rocprofv3 --pmc SQ_INSTS_VALU)" % tag}
+    except Exception:
+        return None
+
+
 def h2d_inclusive(run, pcm, rate, true_peak):
     """Host-buffer entry (what scan_pcm_* / scan_file pay): pinned host -> HBM copy + scan + fetch.
     f32 upload, and S16 upload + on-device widening (the grid scan.c:414 puts every input on)."""
@@ -501,7 +514,8 @@ def main():
                 "tracks_this_rank": len(tracks), "samples_per_step_all_ranks": total_samples,
                 "chunk": info["chunk"], "segments": info["segments"],
             },
-            "roofline": roofline_block(algo_bytes, ks, dt / steps, traffic_from_profiles(workload), timing, kernels),
+            "roofline": dict(roofline_block(algo_bytes, ks, dt / steps, traffic_from_profiles(workload), timing, kernels),
+                             valu_bound=valu_bound_from_profiles(workload)),
             "result": {"loudness": tr["loudness"], "lra": tr["lra"], "peak": tr["peak"],
                        "n_abs": tr["n_abs"], "n_rel": tr["n_rel"], "n_st": tr["n_st"]},
         }
@@ -528,9 +542,10 @@ def main():
         c3 = {"workload": describe(args, "c3", 1, False),
               "value": round(my_samples * c3steps / dt3 / 1e6, 1), "unit": "Msamples/s",
               "steps": c3steps, "ms_per_step": round(dt3 / c3steps * 1e3, 4),
-              "roofline": roofline_block(algo_bytes, ks3, dt3 / c3steps, traffic_from_profiles("c3"),
-                                         "64 serial launches; pipelined timed region",
-                                         "lgd_scan_kernel + lgd_peak_reduce_kernel + lgd_tp_kernel"),
+              "roofline": dict(roofline_block(algo_bytes, ks3, dt3 / c3steps, traffic_from_profiles("c3"),
+                                              "64 serial launches; pipelined timed region",
+                                              "lgd_scan_kernel + lgd_peak_reduce_kernel + lgd_tp_kernel"),
+                               valu_bound=valu_bound_from_profiles("c3")),
               "peak": res3[0][0]["peak"], "true_peak_pruning": "exact; data dependent -- see adversarial"}
         if args.material == "steps" and args.minutes >= 1:
             adv = synth.adversarial_torch(tracks[0].shape[0], 2, device=dev)
