@@ -1127,8 +1127,9 @@ extern "C" hipError_t lgd_launch_tp(int chunk, int nch, int tp, const LgdSeg *se
 }
 
 // chunk lengths compiled in; the host picks one that divides the rate's s100
-// (40, 42, 48, 60, 70 were tried and dropped: their unroll factors spill registers)
-extern "C" const int lgd_chunk_table[] = {25, 35, 45, 49, 50, 63, 75, 0};
+// (40, 42, 48, 60 were tried in round 1 and dropped: their unroll factors spilled registers; 70 came back once the
+// once-per-tile constants had left the SGPRs: no spills at 210 - 247 VGPRs, two waves per SIMD)
+extern "C" const int lgd_chunk_table[] = {25, 35, 45, 49, 50, 63, 70, 75, 0};
 
 
 // F: DEVICE pointer to the group's constants
@@ -1145,6 +1146,7 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, c
       case 49: return launch_scan_strided<49>(nch, tp, segs, n_seg, s);
       case 50: return launch_scan_strided<50>(nch, tp, segs, n_seg, s);
       case 63: return launch_scan_strided<63>(nch, tp, segs, n_seg, s);
+      case 70: return launch_scan_strided<70>(nch, tp, segs, n_seg, s);
       case 75: return launch_scan_strided<75>(nch, tp, segs, n_seg, s);
       default: return hipErrorInvalidValue;
     }
@@ -1164,6 +1166,7 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, c
     case 49: return launch_scan_c<49>(nch, tp, segs, n_seg, s);
     case 50: return launch_scan_c<50>(nch, tp, segs, n_seg, s);
     case 63: return launch_scan_c<63>(nch, tp, segs, n_seg, s);
+    case 70: return launch_scan_c<70>(nch, tp, segs, n_seg, s);
     case 75: return launch_scan_c<75>(nch, tp, segs, n_seg, s);
     default: return hipErrorInvalidValue;
   }

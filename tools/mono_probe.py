@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, "/root/repo")
 import torch
 N_WARM = int(os.environ.get('PROBE_WARM', 100)); N_RUN = int(os.environ.get('PROBE_RUN', 40))
-LAYOUTS = [(48000, int(c)) for c in os.environ.get('PROBE_CH', '1,2').split(',')]
+LAYOUTS = [(int(os.environ.get("PROBE_RATE", 48000)), int(c)) for c in os.environ.get('PROBE_CH', '1,2').split(',')]
 ORDER = [x == 'T' for x in (sys.argv[1] if len(sys.argv) > 1 else 'FT')]
 from loudgain_amd import synth
 from loudgain_amd.device import DeviceScanner
