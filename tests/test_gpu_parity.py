@@ -427,6 +427,17 @@ def test_fuzz_mixed_plans(scanner, oracle, seed):
     for got, ref, s in zip(tracks, refs, specs):
         check_track(got, ref, tp=tp, rate=s[0], lf_tones=True)
     assert len(res) == max(albums) + 1
+    if tp:   # the pruning of the interpolator is exact on every one of these plans too: same floats with it off
+        scanner.set_param("tp_prune", 0)
+        try:
+            tracks0, res0 = scanner.scan([to_dev(p) if p.size else torch_empty(p.shape[1]) for p in pcms],
+                                         [s[0] for s in specs], true_peak=True, albums=albums)
+        finally:
+            scanner.set_param("tp_prune", 1)
+        for a, b in zip(tracks, tracks0):
+            assert a["peak"] == b["peak"] and a["true_peak"] == b["true_peak"] and a["sample_peak"] == b["sample_peak"]
+        for a, b in zip(res, res0):
+            assert a["peak"] == b["peak"]
     for a, album in enumerate(res):
         states = [r["state"] for r, al in zip(refs, albums) if al == a]
         if not states:
