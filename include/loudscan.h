@@ -100,6 +100,10 @@ typedef struct {
 } scan_wav_info;
 int scan_wav_probe(const char *file, scan_wav_info *out);
 long long scan_wav_read_s16(const char *file, short *out, size_t cap_frames);
+/* Per-channel peaks of a scanned file: ebur128_true_peak(state, ch) for every channel, i.e. the values
+ * scan.c:300-307 takes the maximum of (true_peak[ch] = max(interpolated, sample)); sample_peak[ch] is
+ * ebur128_sample_peak.  Either array may be NULL.  Returns the channel count, -1 on a bad index or cap. */
+int scan_get_channel_peaks(unsigned index, double *sample_peak, double *true_peak, unsigned cap);
 /* mark a track's codec (FFmpeg AVCodecID) for callers that decode themselves,
  * e.g. 0x1503C (Opus) to get scan.c's -5 dB pre-gain rule */
 int scan_set_codec(unsigned index, int codec_id, const char *container);

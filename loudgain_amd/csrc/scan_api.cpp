@@ -185,7 +185,13 @@ void upload(Track &t, size_t total, bool as_s16, Fill fill) {
   Dev &d = g_devs[t.gpu];
   HIPFATAL(hipSetDevice(d.hip_id));
   t.dev = (float *)arena_alloc(d, (total ? total : 1) * sizeof(float));
-  const size_t piece = STAGE_BYTES / (as_s16 ? sizeof(short) : sizeof(float));  // multiple of 8 samples
+  // A piece is a whole number of FRAMES (and of 8 samples, which keeps every piece's start 16-B aligned for
+  // the widening kernel): `fill` may come from a sequential reader that delivers whole frames, so a piece
+  // that ended inside a frame would shift everything behind it (round 2 cut at 2^25 samples whatever the
+  // channel count: 3 / 5 / 6 / 7-channel files longer than one piece got their later pieces 2 samples late
+  // -- channels rotated, the last samples lost).
+  size_t piece = STAGE_BYTES / (as_s16 ? sizeof(short) : sizeof(float));
+  piece -= piece % (8 * (size_t)t.channels);
   for (size_t first = 0; first < total; first += piece) {
     const size_t n = std::min(piece, total - first);
     const int b = d.turn;
@@ -613,10 +619,12 @@ extern "C" int scan_file(const char *file, unsigned index) {
   // silence behind, like the reference it is "silently truncated" (its frames stay as announced
   // by the -- already clamped -- data chunk)
   WavReader rd(file, wi);
+  size_t at = 0;  // the reader's position in samples: pieces must arrive in order and frame-aligned
   upload(g_tracks[index], wi.frames * wi.channels, true, [&](void *dst, size_t first, size_t n) {
+    if (first != at || n % wi.channels) fail("scan_file: staging piece [%zu, +%zu) is not where the reader is (%zu)", first, n, at);
     const size_t got = rd.read((short *)dst, n / wi.channels) * wi.channels;
     if (got < n) memset((short *)dst + got, 0, (n - got) * sizeof(short));
-    (void)first;
+    at += n;
   });
   return 0;
 }
@@ -646,6 +654,26 @@ extern "C" scan_result *scan_get_track_result(unsigned index, double pre_gain) {
   r->album_loudness_range = 0.f;
   r->loudness_reference = LUFS_TO_RG(-pre_gain);
   return r;
+}
+
+// ebur128_true_peak per channel, the loop of scan.c:300-307 before its maximum is taken: what a
+// caller (or a test of the channel order) needs to see every channel on its own.  Returns the
+// channel count, -1 for a bad index or too small a `cap`.
+extern "C" int scan_get_channel_peaks(unsigned index, double *sample_peak, double *true_peak, unsigned cap) {
+  if ((int)index >= g_nb) {
+    errmsg("Index too high");
+    return -1;
+  }
+  ensure_scanned();
+  const Track &t = g_tracks[index];
+  if (cap < t.channels) return -1;
+  Dev &d = g_devs[t.gpu];
+  const auto it = std::find(d.tracks.begin(), d.tracks.end(), (int)index);
+  if (it == d.tracks.end()) fail("scan_get_channel_peaks: track %u is not in its GPU's plan", index);
+  HIPFATAL(hipSetDevice(d.hip_id));
+  if (lgd_copy_channel_peaks(d.ctx, (uint32_t)(it - d.tracks.begin()), sample_peak, true_peak, cap))
+    fail("%s", lgd_last_error());
+  return (int)t.channels;
 }
 
 extern "C" int scan_album_has_different_containers(void) {

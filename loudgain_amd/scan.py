@@ -28,7 +28,7 @@ SCAN_SYMBOLS = [
     "scan_album_has_different_containers", "scan_album_has_opus", "scan_file",
     "scan_get_track_result", "scan_get_album_peak", "scan_set_album_result",
     "scan_get_album_result", "scan_set_device", "scan_pcm_s16", "scan_pcm_f32",
-    "scan_pcm_f32_device", "scan_set_codec", "scan_wav_probe", "scan_wav_read_s16", "scan_set_devices",
+    "scan_pcm_f32_device", "scan_set_codec", "scan_wav_probe", "scan_wav_read_s16", "scan_set_devices", "scan_get_channel_peaks",
 ]
 
 
@@ -64,6 +64,7 @@ def _lib_scan():
         L.scan_wav_probe.argtypes = [C.c_char_p, C.POINTER(ScanWavInfo)]
         L.scan_wav_read_s16.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
         L.scan_wav_read_s16.restype = C.c_longlong
+        L.scan_get_channel_peaks.argtypes = [C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint]
         _L = L
     return _L
 
@@ -123,6 +124,16 @@ def scan_wav_read_s16(path, out_ptr, cap_frames):
 
 def scan_set_codec(index, codec_id, container=None):
     return _lib_scan().scan_set_codec(int(index), int(codec_id), container.encode() if container else None)
+
+
+def scan_get_channel_peaks(index):
+    """(sample_peak[ch], true_peak[ch]) of a scanned file, per channel (the values scan.c:300-307 folds)."""
+    sp = (C.c_double * 64)()
+    tp = (C.c_double * 64)()
+    n = _lib_scan().scan_get_channel_peaks(int(index), sp, tp, 64)
+    if n < 0:
+        raise IndexError("scan_get_channel_peaks(%d)" % index)
+    return list(sp[:n]), list(tp[:n])
 
 
 class _OwnedResult:
