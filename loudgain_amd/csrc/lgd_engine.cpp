@@ -27,8 +27,10 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, c
                                       int n_seg, hipStream_t s);
 extern "C" hipError_t lgd_launch_peak_reduce(const LgdTrackMeta *meta, int n_tracks, const float *peaks,
                                              float *hint, hipStream_t s);
-extern "C" hipError_t lgd_launch_tp(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
-                                    int rows_max, const LgdFilt *F, hipStream_t s);
+extern "C" int lgd_tp_instance(int chunk, int *u_out, int *ns_out);
+extern "C" int lgd_tp_magics(int chunk, int nch_wg, int tp, unsigned *magic_nch, unsigned *magic_ns, unsigned *magic_c);
+extern "C" hipError_t lgd_launch_tp(int u, int tp, int ns, const LgdSeg *segs, int n_seg, int rows_max,
+                                    hipStream_t s);
 extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_slices,
                                                 const LgdTrackMeta *meta, int n_tracks,
                                                 const double *E, double *Z, double *st,
@@ -218,6 +220,46 @@ static float interp_prune_factor(int factor) {
   return std::nextafterf(r, 0.f);
 }
 
+// Adjacent-pair bound of the interpolator (lgd_tp_kernel, sparse rows).  Tap k of a phase multiplies x[n - k];
+// the two centre taps kA = HX / 2, kB = kA + 1 (4x: 5, 6 of 12; 2x: 11, 12 of 24) carry most of the phase's
+// weight.  With u = |x[n - kA]|, v = |x[n - kB]|, u + v <= S2, max(u, v) <= M and every other sample <= M:
+//   |y| <= a u + b v + R M <= min(a, b) S2 + (|a - b| + R) M,      R = sum of the other |taps|.
+// out = (alpha2, beta2, alpha1, beta1): the half-sample phase and the quarter-sample phases of the 4x
+// interpolator (2x: its one phase twice), rounded up; out[4] = 1 / (1 + margin) rounded down, the margin
+// (4e-5, as interp_prune_factor) covering the fp32 roundings of the interpolator (< 2e-6 M, and beta >= 0.59)
+// and of the bound's own two FMAs.
+static void interp_pair_bound(int factor, float out[5]) {
+  for (int i = 0; i < 5; ++i) out[i] = 0.f;
+  if (!factor) return;
+  const double pi = 3.14159265358979323846264338327950288;
+  const int ntap = factor == 4 ? 12 : 24, kA = ntap / 2 - 1, kB = ntap / 2;
+  double al[4] = {0, 0, 0, 0}, be[4] = {0, 0, 0, 0};
+  for (int ph = 1; ph < factor; ++ph) {
+    double a = 0, b = 0, rest = 0;
+    for (int k = 0; k < ntap; ++k) {
+      const int j = factor * k + ph;
+      const double m = (double)j - 24.0;
+      double c = 1.0;
+      if (std::fabs(m) > 0.000001) c = std::sin(m * pi / factor) / (m * pi / factor);
+      c *= 0.5 * (1.0 - std::cos(2.0 * pi * j / 48.0));
+      const double ac = std::fabs((double)(float)c) + 1e-9;
+      if (k == kA) a = ac;
+      else if (k == kB) b = ac;
+      else rest += ac;
+    }
+    al[ph] = std::min(a, b);
+    be[ph] = std::fabs(a - b) + rest;
+  }
+  auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, 2.f * f + 1.f); return std::nextafterf(f, 2.f * f + 1.f); };
+  if (factor == 4) {
+    out[0] = up(al[2]); out[1] = up(be[2]);
+    out[2] = up(std::max(al[1], al[3])); out[3] = up(std::max(be[1], be[3]));
+  } else {
+    out[0] = out[2] = up(al[1]); out[1] = out[3] = up(be[1]);
+  }
+  out[4] = std::nextafterf((float)(1.0 / (1.0 + 4e-5)), 0.f);
+}
+
 // ------------------------------------------------------------------ context --
 struct Group {  // tracks sharing (rate, channels, channels per workgroup): one set of kernel constants
   unsigned rate, nch, nch_total;  // nch: channels (waves) per workgroup
@@ -228,6 +270,15 @@ struct Group {  // tracks sharing (rate, channels, channels per workgroup): one 
   size_t seg_begin, seg_count;
   int rows_max;  // most true-peak candidate rows (tiles x channels) of any of its segments
   size_t launch;  // the scan launch its segments go out with
+  int tp_u, tp_ns;  // the lgd_tp_kernel instance of its chunk (lgd_tp_instance)
+};
+// One lgd_tp_kernel launch: every interpolating segment whose (window step, factor, slab steps) instance is
+// the same, whatever its rate, chunk and channel count -- C5's 48 kHz mono / stereo / 5.1 tracks are one
+// launch, its 96 kHz tracks another (nine launches per group became four).  The segments are a second
+// descriptor array in this order (WorkSet::d_segs_tp).
+struct TpLaunch {
+  int u, tp, ns, rows_max;
+  size_t seg_begin, seg_count;
 };
 // One lgd_scan_kernel launch: the groups that run the same kernel instance (chunk, waves per workgroup,
 // staging mode) -- e.g. the 48, 96 and 192 kHz stereo tracks of a plan (C = 75 for all three); the
@@ -243,7 +294,8 @@ static const unsigned LGD_GROUP_CH = 16;  // channels (waves) per workgroup at m
 struct lgd_ctx {
   int device = 0;
   long p_chunk = 0, p_seg_sb = 0, p_warm_sb = 2, p_waves_per_cu = 8, p_debug = 0, p_timing = 1, p_overlap = 0,
-       p_album_slots = 0, p_tp_prune = 1, p_album_world = 8, p_group_streams = 0, p_strided = 1, p_merge = 1;
+       p_album_slots = 0, p_tp_prune = 1, p_album_world = 8, p_group_streams = 0, p_strided = 1, p_merge = 1,
+       p_tp_dense_min = 32;
   int n_cu = 256;
   // plan
   bool planned = false, executed = false;
@@ -251,6 +303,8 @@ struct lgd_ctx {
   std::vector<lgd_track> tracks;
   std::vector<LgdTrackMeta> meta;
   std::vector<LgdSeg> segs;
+  std::vector<LgdSeg> segs_tp;       // the interpolating segments once more, in true-peak launch order
+  std::vector<TpLaunch> tp_launches;
   std::vector<LgdRange> ranges;
   std::vector<LgdSlice> slices;
   std::vector<LgdAlbumMeta> albums;
@@ -273,6 +327,7 @@ struct lgd_ctx {
     float *d_hint = nullptr;        // per track and channel: sample peak of the whole track (LgdSeg::hint)
     unsigned char *d_tp_rows = nullptr;  // chunk maxima, 1 KB per (group of 8 tiles, channel) (LgdSeg::tp_rows)
     LgdSeg *d_segs = nullptr;       // descriptors carry pointers into this set's E / peaks
+    LgdSeg *d_segs_tp = nullptr;    // the same for lgd_tp_kernel's launches (ctx::segs_tp)
     // long loudness-range lists (> LGD_LRA_BIG entries): which ranges, and the scratch of the
     // multi-workgroup kernels (shared by the track launch and the album launch of an execute)
     int *d_big_tr = nullptr, *d_big_al = nullptr, *d_big_one = nullptr;
@@ -286,6 +341,7 @@ struct lgd_ctx {
     uint64_t lra_dist_cap = 0;  // longest gathered album list the scratch holds (multi-GPU form)
     LgdRange *d_ranges = nullptr, *d_album_range = nullptr;
     LgdRange *h_album_range = nullptr;  // pinned
+    size_t cap_segs_tp = 0;
     size_t cap_E = 0, cap_Z = 0, cap_st = 0, cap_res = 0, cap_peaks = 0, cap_segs = 0,
            cap_ranges = 0, cap_p1 = 0, cap_p2 = 0, cap_p2a = 0, cap_rec1 = 0, cap_album = 0,
            cap_part1 = 0, cap_rec2 = 0, cap_heads = 0, cap_album_ranges = 0, cap_pmax = 0, cap_hint = 0, cap_tp_rows = 0;
@@ -311,6 +367,7 @@ struct lgd_ctx {
   // ring of (start, scan kernel done, all done) event triples, one per execute
   static const int EV_RING = 64;
   hipEvent_t ev[EV_RING][4];  // start, scan + true-peak kernels done, all done, scan kernels done
+  bool ev3_valid[EV_RING] = {};
   uint64_t n_exec = 0;
   double abs_gate, rel_factor, minus20;
 };
@@ -379,7 +436,7 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
   (void)hipDeviceSynchronize();
   for (auto &w : c->ws) {
     void *ptrs[] = {w.d_E, w.d_Z, w.d_rec1, w.d_res, w.d_album, w.d_part1, w.d_rec2, w.d_peaks,
-                    w.d_segs, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a, w.d_heads,
+                    w.d_segs, w.d_segs_tp, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a, w.d_heads,
                     w.d_album_ranges, w.d_pmax, w.d_hint, w.d_tp_rows, w.d_big_tr, w.d_big_al, w.d_big_one,
                     w.d_off_tr, w.d_off_al, w.d_off_one, w.d_lra_hist, w.d_lra_part, w.d_lra_cand, w.d_lra_picks};
     for (void *p : ptrs)
@@ -417,6 +474,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "overlap")) c->p_overlap = value;  // 0: every scan on the caller's stream
   else if (!strcmp(name, "album_slots")) c->p_album_slots = value;  // short-term slots of album record 1
   else if (!strcmp(name, "tp_prune")) c->p_tp_prune = value;  // 0: evaluate every interpolator window
+  else if (!strcmp(name, "tp_dense_min")) c->p_tp_dense_min = value;  // rows with >= this many flagged chunks (of 64) are walked whole; 65 = never
   else if (!strcmp(name, "group_streams")) { c->p_group_streams = value; return LGD_OK; }  // 0: groups one after the other
   else if (!strcmp(name, "merge_launches")) c->p_merge = value;  // 1: groups that share a kernel instance go out in one launch
   else if (!strcmp(name, "strided")) c->p_strided = value;  // channel pair / triple workgroups: 0 never, 1 where measured faster, 2 pairs for every 3+ channel layout, 3 triples wherever the count divides
@@ -489,6 +547,8 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   c->meta.assign(n, LgdTrackMeta());
   c->albums.assign(n_albums, LgdAlbumMeta{0, 0, 0, 0});
   c->segs.clear();
+  c->segs_tp.clear();
+  c->tp_launches.clear();
   c->ranges.clear();
   c->slices.clear();
   c->groups.clear();
@@ -705,8 +765,14 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         design_kfilter((double)g.rate, g.F.pb, g.F.pa, g.F.ra);
         design_scan_basis(g.F, g.chunk);
         design_interp(g.tp, g.F.tp);
+        interp_pair_bound(g.tp, g.F.tp + 30);
         g.F.tp_thr = interp_prune_factor(g.tp);
         g.F.tp_prune = c->p_tp_prune ? 1 : 0;
+        g.F.tp_dense_min = (int)c->p_tp_dense_min;
+        g.F.tp_hx = g.tp == 4 ? 11 : (g.tp == 2 ? 23 : 0);
+        g.tp_u = g.tp_ns = 0;
+        if (g.tp && lgd_tp_instance(g.chunk, &g.tp_u, &g.tp_ns))
+          return fail(LGD_EUNSUP, "no true-peak kernel instance for chunk %d", g.chunk);
         g.F.pbn[0] = g.F.pb[1] / g.F.pb[0];
         g.F.pbn[1] = g.F.pb[2] / g.F.pb[0];
         g.F.pb0sq = g.F.pb[0] * g.F.pb[0];
@@ -759,6 +825,11 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         sg.hint = (float *)(uintptr_t)m.hint_off;
         sg.filt = (const void *)(uintptr_t)it->second;  // group index, patched to its device constants
         sg.tp_rows = (void *)~(uintptr_t)0;  // no interpolator: patched to null
+        sg.chunk = g.chunk;
+        sg.nch_wg = (int)g_nch;
+        sg.magic_nch = sg.magic_ns = sg.magic_c = sg.pad_ = 0;
+        if (g.tp && lgd_tp_magics(g.chunk, (int)g_nch, g.tp, &sg.magic_nch, &sg.magic_ns, &sg.magic_c))
+          return fail(LGD_EUNSUP, "true-peak kernel: chunk %d not divisible as needed", g.chunk);
         if (g.tp) {  // one row of candidate bits per tile and channel of this workgroup
           const long long n_tiles = sg.n_tiles;
           const long long rows = n_tiles * (long long)g_nch;
@@ -815,6 +886,24 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     }
     c->launches.swap(sorted);
   }
+  {  // true-peak launches: the interpolating groups by kernel instance, most segments first
+    std::map<std::tuple<int, int, int>, std::vector<size_t>> by_inst;
+    for (size_t gi = 0; gi < c->groups.size(); ++gi)
+      if (c->groups[gi].tp && c->groups[gi].seg_count)
+        by_inst[std::make_tuple(c->groups[gi].tp_u, c->groups[gi].tp, c->groups[gi].tp_ns)].push_back(gi);
+    for (const auto &kv : by_inst) {
+      TpLaunch T{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), 0, c->segs_tp.size(), 0};
+      for (size_t gi : kv.second) {
+        const Group &g = c->groups[gi];
+        T.rows_max = std::max(T.rows_max, g.rows_max);
+        c->segs_tp.insert(c->segs_tp.end(), c->segs.begin() + g.seg_begin, c->segs.begin() + g.seg_begin + g.seg_count);
+      }
+      T.seg_count = c->segs_tp.size() - T.seg_begin;
+      c->tp_launches.push_back(T);
+    }
+    std::stable_sort(c->tp_launches.begin(), c->tp_launches.end(),
+                     [](const TpLaunch &a, const TpLaunch &b) { return a.seg_count > b.seg_count; });
+  }
 
   HIPCHK(hipDeviceSynchronize());  // nothing of an older plan may still be running
   c->n_sets = c->p_overlap ? ((flags & LGD_FLAG_ALBUM_PART1) ? 4 : 2) : 1;
@@ -861,19 +950,21 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if ((rc = ensure(&w.d_res, &w.cap_res, (size_t)n * LGR_STRIDE))) return rc;
     if ((rc = ensure(&w.d_peaks, &w.cap_peaks, c->total_peak_floats))) return rc;
     if ((rc = ensure(&w.d_segs, &w.cap_segs, c->segs.size()))) return rc;
+    if ((rc = ensure(&w.d_segs_tp, &w.cap_segs_tp, c->segs_tp.size()))) return rc;
     if ((rc = ensure(&w.d_tp_rows, &w.cap_tp_rows, (size_t)c->total_tp_rows * 1024))) return rc;
     if ((rc = ensure(&w.d_hint, &w.cap_hint, (size_t)total_ch))) return rc;
     if ((rc = ensure(&w.d_ranges, &w.cap_ranges, n))) return rc;
     // the host descriptors hold offsets; each set gets its own pointers
-    std::vector<LgdSeg> segs(c->segs);
-    for (LgdSeg &sg : segs) {
-      sg.e_out = w.d_E + (uintptr_t)sg.e_out;
-      sg.peak_out = w.d_peaks + (uintptr_t)sg.peak_out;
-      sg.hint = w.d_hint + (uintptr_t)sg.hint;
-      // (sg.tp_rows holds a byte offset; segments of a rate without interpolator get null)
-      sg.tp_rows = sg.tp_rows == (void *)~(uintptr_t)0 ? nullptr : (void *)(w.d_tp_rows + (uintptr_t)sg.tp_rows);
-      sg.filt = c->d_filt + (uintptr_t)sg.filt;
-    }
+    std::vector<LgdSeg> segs(c->segs), segs_tp(c->segs_tp);
+    for (std::vector<LgdSeg> *v : {&segs, &segs_tp})
+      for (LgdSeg &sg : *v) {
+        sg.e_out = w.d_E + (uintptr_t)sg.e_out;
+        sg.peak_out = w.d_peaks + (uintptr_t)sg.peak_out;
+        sg.hint = w.d_hint + (uintptr_t)sg.hint;
+        // (sg.tp_rows holds a byte offset; segments of a rate without interpolator get null)
+        sg.tp_rows = sg.tp_rows == (void *)~(uintptr_t)0 ? nullptr : (void *)(w.d_tp_rows + (uintptr_t)sg.tp_rows);
+        sg.filt = c->d_filt + (uintptr_t)sg.filt;
+      }
     for (uint32_t t = 0; t < n; ++t) {
       c->ranges[t].off = c->meta[t].st_off;
       c->ranges[t].n = c->meta[t].n_st_slots;
@@ -920,6 +1011,8 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     }
     if (!segs.empty())
       HIPCHK(hipMemcpy(w.d_segs, segs.data(), segs.size() * sizeof(LgdSeg), hipMemcpyHostToDevice));
+    if (!segs_tp.empty())
+      HIPCHK(hipMemcpy(w.d_segs_tp, segs_tp.data(), segs_tp.size() * sizeof(LgdSeg), hipMemcpyHostToDevice));
   }
   if (n)
     HIPCHK(hipMemcpy(c->d_meta, c->meta.data(), n * sizeof(LgdTrackMeta), hipMemcpyHostToDevice));
@@ -1064,20 +1157,21 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
     HIPCHK(hipEventRecord(c->ev_gjoin[i], c->gstream[i]));
     HIPCHK(hipStreamWaitEvent(s, c->ev_gjoin[i], 0));
   }
-  if (c->p_timing) HIPCHK(hipEventRecord(ev[3], s));
+  // (the marker between the scan kernels and the true-peak kernels costs ~5 us of queue time -- an event packet
+  // drains the queue -- and sits inside the bracket the roofline is quoted on: only with "timing" 2)
+  if (c->p_timing >= 2) HIPCHK(hipEventRecord(ev[3], s));
+  c->ev3_valid[c->n_exec % lgd_ctx::EV_RING] = c->p_timing >= 2;
   // per-channel sample peaks of the whole tracks, then the interpolator over the chunks that
   // can exceed them
   if (c->flags & LGD_FLAG_TRUE_PEAK)
     HIPCHK(lgd_launch_peak_reduce(c->d_meta, n, w.d_peaks, w.d_hint, s));
-  // One true-peak launch per interpolating group (the kernel's index arithmetic is per chunk length,
-  // channel count and interpolation factor).  (Sending the launches of a mixed plan out on four
-  // streams at once was measured on C5: 2.563 -> 2.546 ms of kernel time, but the event packets
+  // One true-peak launch per kernel instance (window step, interpolation factor, slab steps): chunk length,
+  // channel count and constants travel with the segments.  (Sending the launches of a mixed plan out on
+  // four streams at once was measured on C5: 2.563 -> 2.546 ms of kernel time, but the event packets
   // cost the pipelined step 2.40 -> 2.62 ms: not done.)
-  for (size_t gi = 0; gi < c->groups.size(); ++gi) {
-    const Group &g = c->groups[gi];
-    HIPCHK(lgd_launch_tp(g.chunk, (int)g.nch, g.tp, w.d_segs + g.seg_begin, (int)g.seg_count, g.rows_max,
-                         c->d_filt + gi, s));
-  }
+  if (c->flags & LGD_FLAG_TRUE_PEAK)
+    for (const TpLaunch &T : c->tp_launches)
+      HIPCHK(lgd_launch_tp(T.u, T.tp, T.ns, w.d_segs_tp + T.seg_begin, (int)T.seg_count, T.rows_max, s));
   if (c->p_timing) HIPCHK(hipEventRecord(ev[1], s));
   HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, w.d_E, w.d_Z,
                                    w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_pmax, w.d_res, c->abs_gate,
@@ -1280,6 +1374,8 @@ extern "C" int lgd_scan_only_ms_stats(lgd_ctx *c, uint32_t last_n, float *mean, 
   for (uint64_t i = 0; i < n; ++i) {
     hipEvent_t *ev = c->ev[(c->n_exec - 1 - i) % lgd_ctx::EV_RING];
     float a = 0;
+    if (!c->ev3_valid[(c->n_exec - 1 - i) % lgd_ctx::EV_RING])
+      return fail(LGD_ESTATE, "the scan-kernel marker is only recorded with \"timing\" 2");
     HIPCHK(hipEventSynchronize(ev[2]));
     HIPCHK(hipEventElapsedTime(&a, ev[0], ev[3]));
     sa += a;

@@ -21,14 +21,22 @@ struct LgdSeg {
   int nch_total;         // streams with > 16 channels; otherwise 0 and the channel count)
   int n_tiles;           // tiles of 64 * chunk frames that cover [f0, f_peak_end)
   long long n_frames;    // frames of the whole track (n_floats / channels of the stream)
-  void *tp_rows;         // chunk maxima for lgd_tp_kernel: per group of 8 tiles and channel ch of this
+  void *tp_rows;         // chunk bounds for lgd_tp_kernel: per group of 8 tiles and channel ch of this
                          // workgroup 64 x 16 bytes at byte offset ((k / 8) * nch + ch) * 1024: lane l's
-                         // 8 bf16 values (largest |x| of its chunk in each tile, rounded up; a group of
-                         // n tiles fills the top n slots); null without interpolator
+                         // 8 bf16 values (bound on every interpolator output of its chunk's frames in each
+                         // tile, rounded up; a group of n tiles fills the top n slots); null without interpolator
   float *hint;           // [nch_total] this track's per-channel sample peak (lgd_peak_reduce_kernel): the
                          // bound lgd_tp_kernel prunes with
   const void *filt;      // the LgdFilt of this segment's (rate, chunk) in device memory: per segment, so that
                          // one scan launch can carry the segments of several sample rates
+  // what lgd_tp_kernel needs of the segment's group, here so that its short way to the early exit does not
+  // depend on a second (dependent) load: one true-peak launch carries the segments of several groups
+  int chunk;             // C: frames per lane and tile of the scan kernel that wrote tp_rows
+  int nch_wg;            // channels (waves) per scan workgroup = rows per tile in tp_rows
+  unsigned magic_nch;    // row / nch_wg == umulhi(row, magic_nch) (0: nch_wg == 1)
+  unsigned magic_ns;     // v / (chunk / U) == (v * magic_ns) >> 20 for v < 8 * (chunk / U) + 64
+  unsigned magic_c;      // f / chunk == (f * magic_c) >> 20 for the frame offsets inside a row
+  unsigned pad_;
 };
 
 // Per-(rate, chunk) constants, passed by value as a kernel argument.
@@ -45,12 +53,18 @@ struct LgdFilt {
   double gC[2][4];   // effect of w[0], w[1] of a chunk (C frames) on its end state, scan basis
   double P[6][16];   // transition over C * 2^j frames, j = 0..5 (scan basis, row-major;
                      // block lower triangular: P[.][2], [3], [6], [7] are zero)
-  float tp[36];      // 4x: phases 1..3 x 12 taps; 2x: phase 1 x 24 taps (A.5)
+  float tp[36];      // 4x: [0..11] phase 1, [12..17] phase 2 (first half), [18..29] halved (sum, difference) pairs of
+                     // the mirrored phases 1 / 3; 2x: [0..11] the phase's first half (A.5).  [30..33]: the adjacent-pair
+                     // bound (a2, b2, a1, b1): every output of a window is <= max(a2 S2 + b2 M, a1 S2 + b1 M), M = the
+                     // window's largest |x|, S2 = the largest |x[j]| + |x[j+1]| over the pairs under the two centre taps
+                     // [34]: 1 / (1 + margin) that covers the fp32 roundings of the interpolator and of this bound
   float tp_thr;      // true-peak pruning: a window whose largest |x| is <= tp_thr * (peak found so
                      // far) cannot raise the peak (tp_thr < 1 / max_phase sum |c|, rounding included)
   int tp_prune;      // 0: every window is evaluated (reference mode of the pruning tests)
   int lps;           // lanes (C-frame chunks) per 100 ms sub-block = s100 / C
   int pad;           // debug builds: floor-measurement mode bits
+  int tp_dense_min;  // lgd_tp_kernel: rows with at least this many flagged chunks (of 64) are walked as a whole
+  int tp_hx;         // frames of history an interpolator output reads: 11 (4x), 23 (2x), 0 (none)
   int pskip;         // bit j: P[j]'s shelf block (entries 10,11,14,15) is < 1e-19 -> skipped
   int s100;          // frames per 100 ms sub-block (generic kernel: any alignment)
 };

@@ -250,7 +250,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // (true peak: this kernel only records every chunk's largest |x|; lgd_tp_kernel decides from
   // them which interpolator outputs can matter and evaluates those)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 mc_rows = (u32x4)(0u);  // this lane's chunk maxima of the last 8 tiles (bf16, newest on top)
+  u32x4 mc_rows = (u32x4)(0u);  // this lane's chunk bounds of the last 8 tiles (bf16, newest on top)
+  float car_m = 0.f, car_p = 0.f;  // wave-uniform: largest |x| / adjacent-pair sum of the chunk in front of lane 0's
   // where this lane's next record goes: [group of 8 tiles][channel][lane] (a per-lane pointer in
   // VGPRs: the scalar form kept the base and the group index live in SGPRs through the tile loop)
   u32x4 LGD_GLOBAL *row_p = (u32x4 LGD_GLOBAL *)sg.tp_rows + (ch * LGD_WAVE + lane);
@@ -262,7 +263,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // wave waits for it.  Measured run to run, the true-peak variant of the stereo kernel was 0 to
   // 6 % slower than the plain one with one store per 8 tiles; 5.1 as triples with true peak 0.388 ->
   // 0.367 ms, 7.1 0.399 -> 0.393 ms for 345.6 M samples.)
-  constexpr int LGD_ROW_PARK = (TP != 0 && ((G >= 1 && G <= 2) || (G == 3 && STR) || G == 8)) ? 5 : 0;
+  constexpr int LGD_ROW_PARK = (TP != 0 && ((G >= 1 && G <= 2) || G == 8)) ? 5 : ((TP != 0 && G == 3 && STR) ? 2 : 0);
   u32x4 parked[LGD_ROW_PARK + 1];
 #pragma unroll
   for (int i = 0; i < LGD_ROW_PARK; ++i) parked[i] = (u32x4)(0u);
@@ -603,9 +604,18 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       bnd = rem < (unsigned)C ? (int)rem : C;
     }
     float mc = 0.f;  // largest |x| of this lane's chunk
+    // true-peak variants: largest |x[j]| + |x[j-1]| over the chunk's frames j (the first frame pairs with the
+    // last of the chunk before): what the adjacent-pair bound of the interpolator is made of (see below)
+    float pp = 0.f, xlast = (TP != 0) ? fabsf(LGD_X(-1)) : 0.f;
 #define LGD_STEP_PEAKS(xs, step_)                                                       \
     do {                                                                                \
-      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) mc = fmaxf(mc, fabsf((xs)[u_])); \
+      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                                \
+        mc = fmaxf(mc, fabsf((xs)[u_]));                                                \
+        if constexpr (TP != 0) {                                                        \
+          pp = fmaxf(pp, fabsf((xs)[u_]) + xlast);                                      \
+          xlast = fabsf((xs)[u_]);                                                      \
+        }                                                                               \
+      }                                                                                 \
     } while (0)
     if (filt) {
       double xh[2], eh = 0.0, en = 0.0;
@@ -663,18 +673,48 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 #undef LGD_STEP_PEAKS
 
     pk_s = fmaxf(pk_s, mc);
-    // ---- true peak: hand this tile's chunk maxima to lgd_tp_kernel (one float per lane, one
-    // 256-B row per wave and tile); it decides with the channel's final peak which chunks'
-    // interpolator outputs can matter at all (exact pruning).  (Evaluating the
-    // interpolator here, with the tile still in LDS, was measured: loud passages cluster in
-    // time, the workgroup that owns one then runs long after the other 999 have finished,
-    // and the kernel takes as long as that workgroup.  The follow-up kernel spreads the
-    // chunks that matter over the whole GPU.)
+    // ---- true peak: hand lgd_tp_kernel, per chunk, a BOUND on every interpolator output of the chunk's
+    // frames (one bf16 per lane and tile); with the channel's final sample peak it decides which chunks'
+    // outputs can matter at all (exact pruning).  An output is sum_k c_k x[n-k] with two dominant centre
+    // taps, so |y| <= a S2 + b M for M = the largest |x| it reads and S2 = the largest |x[j]| + |x[j-1]| under
+    // the centre taps (lgd_engine.cpp interp_pair_bound): 1.4 M for an isolated peak, where the plain L1 M
+    // is 1.86 M -- on noise that flags 40 times fewer chunks, and the flagged chunks are what the
+    // true-peak kernel has to fetch again (with L1 M: 0.8 GB of the 1.4 GB of a 60 min noise track).  M and
+    // S2 are taken over this chunk and the one before it (the outputs read HX frames of that; lane 0: the
+    // last chunk of the previous tile; in front of the segment: the HX frames kept before the tile).
+    // (Evaluating the interpolator here, with the tile still in LDS, was measured: loud passages cluster
+    // in time, the workgroup that owns one then runs long after the other 999 have finished, and the kernel
+    // takes as long as that workgroup.  The follow-up kernel spreads the chunks that matter over the GPU.)
     if constexpr (TP != 0) {
-      // this tile's chunk maximum, rounded UP to bf16 (a bound may only grow), enters the
-      // 8 x 16-bit shift register of the last tiles (stored every 8 tiles / behind the loop)
+      if (k == 0) {  // history in front of the segment (zeros in front of the track)
+        const int hx = Fk->tp_hx;
+        if (hx <= K::HALO) {
+          float hm = 0.f, hp = 0.f, hl = fabsf(LGD_X(-K::HALO));
+#pragma unroll
+          for (int j = K::HALO - 1; j >= 1; --j) {
+            const float a = fabsf(LGD_X(-j));
+            hm = fmaxf(hm, a);
+            hp = fmaxf(hp, a + hl);
+            hl = a;
+          }
+          car_m = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hm)));
+          car_p = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hp)));
+        } else {  // (2x interpolator: 23 frames of history, more than the tile keeps: nothing known)
+          car_m = car_p = __builtin_inff();
+        }
+      }
+      const float mprev = __int_as_float(__builtin_amdgcn_update_dpp(
+          __float_as_int(car_m), __float_as_int(mc), 0x138, 0xf, 0xf, false));  // wave_shr:1, lane 0 <- carry
+      const float pprev = __int_as_float(__builtin_amdgcn_update_dpp(
+          __float_as_int(car_p), __float_as_int(pp), 0x138, 0xf, 0xf, false));
+      car_m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mc), LGD_WAVE - 1));
+      car_p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pp), LGD_WAVE - 1));
+      const float M = fmaxf(mc, mprev), S2 = fmaxf(pp, pprev);
+      const float bnd = fmaxf(fmaf(Fk->tp[30], S2, Fk->tp[31] * M), fmaf(Fk->tp[32], S2, Fk->tp[33] * M));
+      // rounded UP to bf16 (a bound may only grow), into the 8 x 16-bit shift register of the last
+      // tiles (stored every 8 tiles / behind the loop)
       {
-        const unsigned code = (__float_as_uint(mc) + 0xFFFFu) >> 16;
+        const unsigned code = (__float_as_uint(bnd) + 0xFFFFu) >> 16;
         mc_rows.x = __builtin_amdgcn_alignbit(mc_rows.y, mc_rows.x, 16);
         mc_rows.y = __builtin_amdgcn_alignbit(mc_rows.z, mc_rows.y, 16);
         mc_rows.z = __builtin_amdgcn_alignbit(mc_rows.w, mc_rows.z, 16);
@@ -786,14 +826,25 @@ extern "C" hipError_t lgd_launch_peak_reduce(const LgdTrackMeta *meta, int n_tra
 // E4 (ebur128_check_true_peak / interp_process, reached from scan.c:448) for the chunks that
 // can still raise the peak.  Row r of a segment = (tile k = r / nch, channel r mod nch): 64
 // values, entry l = the largest |x| of lane l's chunk (rounded up to bf16), the C frames
-// [tb + l C, + C) of the tile, tb = f0 + k * 64 C.  One wave per row.  The row's flagged chunks are staged LGD_TP_GROUP at a
-// time -- each with the HX frames before it, coalesced loads that mostly hit L2 / Infinity
-// Cache, the scan kernel has just streamed those lines; the next group is in flight while one
-// is evaluated -- and a lane takes one (chunk, step) slot of the group: U output frames from
-// U + HX staged ones, whatever chunk they belong to, so isolated chunks fill passes as well
-// as a loud passage does.  The bound is re-checked against the channel's FINAL peak hint
-// (a pass none of whose lanes can exceed it is skipped) and the non-trivial polyphase
-// branches are evaluated in fp32 (the reference: float data, double
+// [tb + l C, + C) of the tile, tb = f0 + k * 64 C.  One wave per row; the chunks whose outputs
+// could exceed the channel's final sample peak (L1 * max|x| of the chunk and the one before it) are
+// "flagged".  Two ways through a row:
+//   sparse (few flagged chunks): the flagged chunks are staged LGD_TP_GROUP at a time -- each with
+//     the HX frames before it, eight lanes per chunk, the next group in flight while one is
+//     evaluated -- and a lane takes one (chunk, step) slot of the group: U output frames from U + HX
+//     staged ones, whatever chunk they belong to, so isolated chunks fill passes as well as a
+//     loud passage does.  A pass is evaluated only if one of its windows can exceed the peak by the
+//     ADJACENT-PAIR bound: an output is sum_k c_k x[n-k] with two dominant centre taps, so
+//     |y| <= a S2 + b M (M the window's largest |x|, S2 its largest |x[j]| + |x[j+1]| under the centre
+//     taps) -- 1.4 M for an isolated peak where L1 M is 1.86 M: on noise nearly every staged window
+//     is dismissed by ~20 instructions instead of the ~150 of the interpolator;
+//   dense (>= tp_dense_min flagged chunks: loud tones, limited music): the row is walked as a
+//     whole in slabs of 64 x LP contiguous frames -- one contiguous copy global -> LDS, no per-chunk
+//     addressing -- and every lane slides a register window over its LP frames: one LDS read and the
+//     ~29 interpolator instructions per output frame (the sparse form re-reads 16 window values per
+//     5 outputs and pays its index arithmetic per pass).  Chunks that were not flagged are evaluated
+//     along: any interpolator output is a true output, the maximum cannot change.
+// The non-trivial polyphase branches are evaluated in fp32 (the reference: float data, double
 // accumulate, float result; difference <= 2e-7 against a bar of 1e-4):
 //   4x: phases 1 and 3 mirror each other, phase 2 is symmetric: six (sum, difference) pairs of
 //       window samples feed one packed FMA for (y1 + y3, y1 - y3) / 2 and one FMA for y2 --
@@ -804,83 +855,108 @@ extern "C" hipError_t lgd_launch_peak_reduce(const LgdTrackMeta *meta, int n_tra
 // folded into the segment's interpolated peak with an atomic max on the float bits
 // (non-negative floats order like their bits).
 #define LGD_TP_WAVES 4
-#define LGD_TP_GROUP 8     // flagged chunks staged together
+#define LGD_TP_GROUP 8     // accepted chunks evaluated together (sparse rows)
 #define LGD_TP_CHMAX 100   // frames of one staged chunk at most: C + HX
-#define LGD_TP_NPRE ((LGD_TP_GROUP * LGD_TP_CHMAX + LGD_WAVE - 1) / LGD_WAVE)
-template <int U, int TP>
-__global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
-    const LgdSeg *__restrict__ segs, const LgdFilt *__restrict__ Fg, const int C, const int nch,
-    const unsigned magic_ch, const unsigned magic_ns, const unsigned magic_nch) {
-  constexpr int HX = (TP == 2) ? 23 : 11;
-  // per wave: the ids of the row's flagged chunks, and the staged frames of one group of them
-  // (chunk c of the group at [c * (C + HX), + C + HX): its HX frames of history, then its own)
-  __shared__ unsigned char chunk_of[LGD_TP_WAVES][LGD_WAVE];
-  __shared__ float stage[LGD_TP_WAVES][LGD_TP_NPRE * LGD_WAVE];  // (whole rounds of 64 lanes are stored)
+#define LGD_TP_AHEAD 3     // sparse rows: flagged chunks whose loads are in flight ahead of the one being looked at
+// U frames per window step, TP interpolation factor, NS steps per lane of a dense slab (LP = U NS frames)
+template <int U, int TP, int NS>
+struct TpCfg {
+  static constexpr int HX = (TP == 2) ? 23 : 11;
+  static constexpr int LP = U * NS;
+  static constexpr int NPRE_D = LP + 1;                       // rounds of 64 that cover 64 LP + HX slab frames
+  static constexpr int BUF_D = NPRE_D * LGD_WAVE, BUF_S = LGD_TP_GROUP * LGD_TP_CHMAX;
+  static constexpr int BUF = BUF_D > BUF_S ? BUF_D : BUF_S;   // floats of LDS per wave
+};
+
+// rows one wave takes: r = w + i * (waves per segment), i < LGD_TP_RPW.  The loads that decide a row's fate
+// (its channel's peak, the segment's peak, the row's record) are all in flight at once, so a wave costs one
+// memory latency whatever LGD_TP_RPW is -- and the kernel's fixed cost, the sweep over rows with nothing to do
+// (72 000 of them in C3: 11.7 us at one row per wave), falls with the number of waves.  Consecutive rows go to
+// different waves: a loud passage (consecutive tiles) is spread over a segment's waves.
+#ifndef LGD_TP_RPW
+#define LGD_TP_RPW 1
+#endif
+template <int U, int TP, int NS>
+__global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const LgdSeg *__restrict__ segs) {
+  using K = TpCfg<U, TP, NS>;
+  constexpr int HX = K::HX, LP = K::LP;
+  constexpr int PK = (HX - 1) / 2;  // window index of the older of the two centre-tap samples of output 0
+  // per wave: the ids of the chunks of the group being evaluated, and the staged frames (a group of accepted
+  // chunks: chunk c at [c * (C + HX), + C + HX), its HX frames of history first; or one slab of a dense row)
+  __shared__ unsigned char chunk_of[LGD_TP_WAVES][LGD_TP_GROUP];
+  __shared__ float stage[LGD_TP_WAVES][K::BUF];
   typedef const LgdFilt __attribute__((address_space(4))) *cfilt_ptr;
-  const cfilt_ptr F0 = (cfilt_ptr)Fg;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & (LGD_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const LgdSeg sg = segs[blockIdx.x];
+  const cfilt_ptr F0 = (cfilt_ptr)sg.filt;
+  const int C = sg.chunk, nch = sg.nch_wg;
   const long long tile_f = (long long)LGD_WAVE * C;
   const int n_main = sg.n_tiles;
-  const int row = blockIdx.y * LGD_TP_WAVES + wave;
-  if (row >= n_main * nch) return;  // wave-uniform
-  // (the way to the early exit below is kept short: every row of the plan comes through here)
-  const int k = magic_nch ? (int)__umulhi((unsigned)row, magic_nch) : row;  // row / nch
-  const int ch = row - k * nch;
+  const int n_rows = n_main * nch;
+  const int wps = (int)gridDim.y * LGD_TP_WAVES;  // waves per segment
+  const int w_seg = (int)blockIdx.y * LGD_TP_WAVES + wave;
+  if (w_seg >= n_rows) return;  // wave-uniform
   const int nch_tot = sg.nch_total ? sg.nch_total : nch;
-  const int chan = sg.ch0 + ch;  // channel of the stream (channel groups of wide streams: ch0 > 0)
   const long long n_frames = sg.n_frames;
-  const long long tb = sg.f0 + (long long)k * tile_f;
-  const gflt_ptr pcm = (gflt_ptr)sg.pcm + chan;
   const int CH = C + HX, NSTEP = C / U;
+  const int prune = F0->tp_prune;
+  const float f_thr = F0->tp_thr, f_pthr = F0->tp[34];
 
-
-  // Exact pruning: an interpolated output is sum_k c_k x[n-k], so it cannot exceed L1 * (largest
-  // |x| it reads), L1 = largest sum |c_k| of a phase.  sg.hint holds this channel's sample peak
-  // over the whole track (lgd_peak_reduce): outputs with L1 * max|x| <= it cannot raise
-  // max(true peak, sample peak) -- the value ebur128_true_peak reports (E9) -- and are not
-  // evaluated.  The result is bit-identical to evaluating everything (tp_prune 0: thr < 0).
-  float thr = -1.f;
-  if (F0->tp_prune) thr = ((const float LGD_GLOBAL *)sg.hint)[chan] * F0->tp_thr;
-  // A whole segment whose sample peak (exact, written by the scan kernel) stays at or below the
-  // threshold has no chunk that can matter -- except the first of its first tile, whose history
-  // lies in front of the segment: rows of later tiles leave before reading their record.
-  if (k > 0 && !(((const float LGD_GLOBAL *)sg.peak_out)[chan] > thr)) return;
-  // Which chunks can matter: the interpolator outputs of lane l's chunk read its own frames and
-  // the last HX of the chunk before it, so they are bounded by L1 * max(mc[l], mc[l - 1]) (mc =
-  // the chunk maxima the scan kernel stored; the chunk before lane 0 is lane 63 of the previous
-  // tile's row -- in front of a segment's first tile nothing is known: +inf).
-  unsigned long long mask;
-  {
-    // tile k's maxima: group g = k / 8, 16-bit slot `slot` of every lane's 16 bytes (the scan
-    // kernel shifts new tiles in at the top: a group of n tiles fills slots 8 - n .. 7)
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 LGD_GLOBAL *rows = (const u32x4 LGD_GLOBAL *)sg.tp_rows;
-    const int g = k >> 3, g_last = (n_main - 1) >> 3;
-    const int n_in = g == g_last ? ((n_main - 1) & 7) + 1 : 8;
-    const int slot = 8 - n_in + (k & 7);
-    const u32x4 mine = rows[((size_t)g * nch + ch) * LGD_WAVE + lane];
-    auto code_at = [](const u32x4 v, const int sl) -> float {  // (sl is wave-uniform)
-      const unsigned w = (sl >> 1) == 0 ? v.x : ((sl >> 1) == 1 ? v.y : ((sl >> 1) == 2 ? v.z : v.w));
-      return __uint_as_float(((sl & 1) ? (w >> 16) : (w & 0xffffu)) << 16);
-    };
-    const float mc = code_at(mine, slot);
-    float carry = __builtin_inff();  // in front of a segment's first tile nothing is known
-    if (k > 0) {
-      if ((k & 7) != 0) {
-        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(code_at(mine, slot - 1)), LGD_WAVE - 1));
-      } else {
-        const u32x4 prev = rows[((size_t)(g - 1) * nch + ch) * LGD_WAVE + (LGD_WAVE - 1)];
-        carry = code_at(prev, 7);
-      }
-    }
-    const float mprev = __int_as_float(__builtin_amdgcn_update_dpp(
-        __float_as_int(carry), __float_as_int(mc), 0x138, 0xf, 0xf, false));  // wave_shr:1
-    mask = __ballot(fmaxf(mc, mprev) > thr);
+  // Exact pruning.  sg.hint holds each channel's sample peak P over the whole track (lgd_peak_reduce), and
+  // what ebur128_true_peak reports (E9) is max(true peak, sample peak): outputs that cannot exceed P cannot
+  // change it and are not evaluated -- the result is bit-identical to evaluating everything (tp_prune 0:
+  // thresholds < 0).  Two bounds, margins for the fp32 roundings included (lgd_engine.cpp):
+  //   L1 * (largest |x| an output reads), L1 = largest sum |c_k| of a phase: `thr`, for whole segments;
+  //   the adjacent-pair bound a S2 + b M: `pthr`, per chunk (recorded by the scan kernel) and per window.
+  // Row r = (tile k = r / nch, channel r mod nch).  Its record: group g = k / 8 of the segment's tiles, 16-bit
+  // slot `slot` of every lane's 16 bytes (the scan kernel shifts new tiles in at the top: a group of n tiles
+  // fills slots 8 - n .. 7); entry l bounds every interpolator output of lane l's chunk.
+  // A whole segment whose sample peak (exact, written by the scan kernel) stays at or below the L1 threshold
+  // has no chunk that can matter -- except the first of its first tile, whose history lies in front of it.
+  u32x4 rec[LGD_TP_RPW];
+  float rP[LGD_TP_RPW], rS[LGD_TP_RPW];
+  int rk[LGD_TP_RPW], rchan[LGD_TP_RPW], rslot[LGD_TP_RPW];
+  const int g_last = (n_main - 1) >> 3;
+#pragma unroll
+  for (int i = 0; i < LGD_TP_RPW; ++i) {
+    const int row = w_seg + i * wps;
+    const bool on = row < n_rows;  // (wave-uniform)
+    const int rr = on ? row : 0;
+    const int k = sg.magic_nch ? (int)__umulhi((unsigned)rr, sg.magic_nch) : rr;  // row / nch
+    const int ch = rr - k * nch;
+    rk[i] = on ? k : -1;
+    rchan[i] = sg.ch0 + ch;  // channel of the stream (channel groups of wide streams: ch0 > 0)
+    const int g_ = k >> 3;
+    const int n_in = g_ == g_last ? ((n_main - 1) & 7) + 1 : 8;
+    rslot[i] = 8 - n_in + (k & 7);
+    rP[i] = ((const float LGD_GLOBAL *)sg.hint)[rchan[i]];
+    rS[i] = ((const float LGD_GLOBAL *)sg.peak_out)[rchan[i]];
+    rec[i] = ((const u32x4 LGD_GLOBAL *)sg.tp_rows)[((size_t)g_ * nch + ch) * LGD_WAVE + lane];
   }
-  const int n_chunks = __popcll(mask);
-  if (n_chunks == 0) return;
+  // lane i keeps what row i needs later: the loop over the wave's rows below is not unrolled
+  unsigned v_mlo = 0u, v_mhi = 0u;
+  int v_k = -1, v_chan = 0;
+  float v_pthr = -1.f;
+  bool any_row = false;
+#pragma unroll
+  for (int i = 0; i < LGD_TP_RPW; ++i) {
+    const float thr = prune ? rP[i] * f_thr : -1.f, pthr = prune ? rP[i] * f_pthr : -1.f;
+    unsigned long long m = 0ull;
+    if (rk[i] >= 0 && (rk[i] == 0 || rS[i] > thr)) {
+      const int slot = rslot[i];
+      const unsigned w = (slot >> 1) == 0 ? rec[i].x : ((slot >> 1) == 1 ? rec[i].y : ((slot >> 1) == 2 ? rec[i].z : rec[i].w));
+      const float bnd = __uint_as_float(((slot & 1) ? (w >> 16) : (w & 0xffffu)) << 16);
+      m = __ballot(bnd > pthr);
+    }
+    any_row = any_row || m != 0ull;
+    if (lane == i) {
+      v_mlo = (unsigned)m; v_mhi = (unsigned)(m >> 32);
+      v_k = rk[i]; v_chan = rchan[i]; v_pthr = pthr;
+    }
+  }
+  if (!any_row) return;
   float tpa[12 + 1], tpb[6 + 1];
   f32x2 tpsd[6 + 1];  // 4x: halved (sum, difference) coefficients of the mirrored phase pair
 #pragma unroll
@@ -890,113 +966,239 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(
 #pragma unroll
   for (int i = 0; i < (TP == 4 ? 6 : 0); ++i) tpb[i] = F0->tp[12 + i];
   (void)tpa; (void)tpb; (void)tpsd;
-  // entry o of the table: the o-th set bit of the mask
-  if ((mask >> lane) & 1ull)
-    chunk_of[wave][__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // element e of group g: chunk c = e / CH of the group, frame j = e % CH of its span;
-  // frames outside the track read as zero
-  auto fetch_group = [&](const int g, float (&pre)[LGD_TP_NPRE]) {
-    const int n = min(LGD_TP_GROUP, n_chunks - g * LGD_TP_GROUP);
-    const int E = n * CH;
+  const int dense_min = F0->tp_dense_min;
+  const float pa2 = F0->tp[30], pb2 = F0->tp[31], pa1 = F0->tp[32], pb1 = F0->tp[33];
+  float *const buf = stage[wave];
+#pragma nounroll
+  for (int ri = 0; ri < LGD_TP_RPW; ++ri) {
+  const unsigned long long mask = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v_mlo, ri) |
+                                  ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v_mhi, ri) << 32);
+  if (mask == 0ull) continue;
+  const int k = __builtin_amdgcn_readlane(v_k, ri);
+  const int chan = __builtin_amdgcn_readlane(v_chan, ri);
+  const float pthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v_pthr), ri));
+  const long long tb = sg.f0 + (long long)k * tile_f;
+  const gflt_ptr pcm = (gflt_ptr)sg.pcm + chan;
+  const int n_chunks = __popcll(mask);
+  // the interpolator over one window: wv[i] = x[n0 - HX + i] -> m_[u] = max over the non-trivial phases of
+  // |y(n0 + u)|, u < U
+  auto fir = [&](const float (&wv)[U + HX], float (&m_)[U]) {
+    if constexpr (TP == 4) {
+      f32x2 sd_[U];
+      float o2_[U];
 #pragma unroll
-    for (int r = 0; r < LGD_TP_NPRE; ++r) {
-      const int e = r * LGD_WAVE + lane;
-      float v = 0.f;
-      if (r * LGD_WAVE < E) {  // (wave-uniform)
-        const int ee = e < E ? e : 0;
-        const int c = (int)(((unsigned)ee * magic_ch) >> 20);
-        const int j = ee - c * CH;
-        const long long f = tb + (long long)chunk_of[wave][g * LGD_TP_GROUP + c] * C - HX + j;
-        const bool in = e < E && f >= 0 && f < n_frames;
-        v = in ? pcm[(in ? f : 0) * nch_tot] : 0.f;
+      for (int u_ = 0; u_ < U; ++u_) { sd_[u_] = (f32x2){0.f, 0.f}; o2_[u_] = 0.f; }
+#pragma unroll
+      for (int k_ = 0; k_ < 6; ++k_) {
+        const f32x2 csd_ = tpsd[k_];
+        const float c2_ = tpb[k_];
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_) {
+          const float xa_ = wv[HX + u_ - k_], xb_ = wv[u_ + k_];
+          const f32x2 ab_ = (f32x2){xa_ + xb_, xa_ - xb_};
+          sd_[u_] = __builtin_elementwise_fma(csd_, ab_, sd_[u_]);
+          o2_[u_] = fmaf(c2_, ab_.x, o2_[u_]);
+        }
       }
-      pre[r] = v;
+#pragma unroll
+      for (int u_ = 0; u_ < U; ++u_) m_[u_] = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));
+    } else {
+      float o1_[U];
+#pragma unroll
+      for (int u_ = 0; u_ < U; ++u_) o1_[u_] = 0.f;
+#pragma unroll
+      for (int k_ = 0; k_ < 12; ++k_) {
+        const float c1_ = tpa[k_];
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_) o1_[u_] = fmaf(c1_, wv[HX + u_ - k_] + wv[u_ + k_], o1_[u_]);
+      }
+#pragma unroll
+      for (int u_ = 0; u_ < U; ++u_) m_[u_] = fabsf(o1_[u_]);
     }
   };
   float pk_t = 0.f;
-  float pre[LGD_TP_NPRE];
-  const int n_groups = (n_chunks + LGD_TP_GROUP - 1) / LGD_TP_GROUP;
-  fetch_group(0, pre);
-  float *const buf = stage[wave];
-  for (int g = 0; g < n_groups; ++g) {
-    const int n = min(LGD_TP_GROUP, n_chunks - g * LGD_TP_GROUP);
-    // (every lane is done reading the previous group: the wave runs in lockstep through the
-    // loop below and the fences order its LDS traffic)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+
+  if (n_chunks >= dense_min) {
+    // ---------------------------------------------------------------- dense row
+    // slabs of 64 x LP contiguous frames from the start of the row (the last one may reach past its end, into
+    // the next tile's frames: true outputs too); slab s covers frames [s 64 LP, (s + 1) 64 LP) of the row,
+    // i.e. chunks floor(s 64 LP / C) .. floor(((s + 1) 64 LP - 1) / C), and is walked if one of them is flagged
+    const int n_slabs = (C + LP - 1) / LP;
+    auto slab_wanted = [&](const int s) -> bool {
+      const unsigned a = (unsigned)(s * (LGD_WAVE * LP)), b = a + (unsigned)(LGD_WAVE * LP - 1);
+      const unsigned c0 = (a * sg.magic_c) >> 20;
+      unsigned c1 = (b * sg.magic_c) >> 20;
+      c1 = c1 > 63u ? 63u : c1;
+      const unsigned long long span = (c1 - c0 == 63u) ? ~0ull : (((1ull << (c1 - c0 + 1u)) - 1ull) << c0);
+      return (mask & span) != 0ull;
+    };
+    auto next_slab = [&](int s) -> int {
+      while (s < n_slabs && !slab_wanted(s)) ++s;
+      return s;
+    };
+    float pre[K::NPRE_D];
+    // element e = r * 64 + lane of slab s is frame tb + s * 64 LP - HX + e (the rounds past the slab's
+    // 64 LP + HX elements are staged along, never read)
+    auto fetch_slab = [&](const int s) {
+      const long long f_first = tb + (long long)s * (LGD_WAVE * LP) - HX;
+      if (f_first >= 0 && f_first + (long long)K::NPRE_D * LGD_WAVE <= n_frames) {  // (wave-uniform) interior
+        gflt_ptr src = pcm + f_first * nch_tot;
+        const unsigned lo = (unsigned)(lane * nch_tot);
 #pragma unroll
-    for (int r = 0; r < LGD_TP_NPRE; ++r)
-      if (r * LGD_WAVE < n * CH) buf[r * LGD_WAVE + lane] = pre[r];
-    if (g + 1 < n_groups) fetch_group(g + 1, pre);  // in flight while this group is evaluated
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // lane slot v = (chunk c of the group, step st): the U output frames c's frames [st U, + U)
-    const int S = n * NSTEP;
-    for (int v0 = 0; v0 < S; v0 += LGD_WAVE) {
-      const int v = v0 + lane;
-      const bool act = v < S;
-      const int vv = act ? v : 0;
-      const int c = (int)(((unsigned)vv * magic_ns) >> 20);
-      const int st = vv - c * NSTEP;
-      const float *w0 = buf + c * CH + st * U;  // frame (st U - HX) of the chunk
+        for (int r = 0; r < K::NPRE_D; ++r) {
+          gflt_ptr src_r = src + (long long)(r * LGD_WAVE) * nch_tot;
+          asm volatile("" : "+s"(src_r));  // scalar base + 32-bit lane offset
+          pre[r] = src_r[lo];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < K::NPRE_D; ++r) {
+          const long long f = f_first + r * LGD_WAVE + lane;
+          const bool in = f >= 0 && f < n_frames;
+          pre[r] = in ? pcm[(in ? f : 0) * nch_tot] : 0.f;
+        }
+      }
+    };
+    int s = next_slab(0);
+    if (s < n_slabs) fetch_slab(s);
+    while (s < n_slabs) {
+      // (every lane is done reading the previous slab: the wave runs in lockstep and the fences
+      // order its LDS traffic)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < K::NPRE_D; ++r) buf[r * LGD_WAVE + lane] = pre[r];
+      const int s_next = next_slab(s + 1);
+      if (s_next < n_slabs) fetch_slab(s_next);  // in flight while this slab is walked
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // lane l: output frames fl + [0, LP), fl = tb + s * 64 LP + l * LP; window element 0 = frame fl - HX
+      // = slab element l * LP (odd lane stride: conflict-free)
+      const float *w0 = buf + lane * LP;
+      const long long fl = tb + (long long)s * (LGD_WAVE * LP) + (long long)lane * LP;
+      const long long rem_ll = n_frames - fl;  // outputs at or past the end of the track do not exist
+      const int rem = rem_ll >= LP ? LP : (rem_ll < 0 ? 0 : (int)rem_ll);
+      const bool whole = __all(rem == LP);
       float wv[U + HX];
 #pragma unroll
-      for (int i = 0; i < U + HX; ++i) wv[i] = w0[i];
-      float wm = 0.f;
+      for (int i = 0; i < HX; ++i) wv[i] = w0[i];
 #pragma unroll
-      for (int i = 0; i < U + HX; ++i) wm = fmaxf(wm, fabsf(wv[i]));
-      const bool need = act && (wm > thr);
-      if (!__any(need)) continue;  // wave-uniform: nothing in this pass can exceed the final peak
-      float m_[U];
-      if constexpr (TP == 4) {
-        f32x2 sd_[U];
-        float o2_[U];
+      for (int st = 0; st < NS; ++st) {
 #pragma unroll
-        for (int u_ = 0; u_ < U; ++u_) { sd_[u_] = (f32x2){0.f, 0.f}; o2_[u_] = 0.f; }
+        for (int u_ = 0; u_ < U; ++u_) wv[HX + u_] = w0[HX + st * U + u_];
+        float m_[U];
+        fir(wv, m_);
+        if (whole) {
 #pragma unroll
-        for (int k_ = 0; k_ < 6; ++k_) {
-          const f32x2 csd_ = tpsd[k_];
-          const float c2_ = tpb[k_];
+          for (int u_ = 0; u_ < U; ++u_) pk_t = fmaxf(pk_t, m_[u_]);
+        } else {
 #pragma unroll
-          for (int u_ = 0; u_ < U; ++u_) {
-            const float xa_ = wv[HX + u_ - k_], xb_ = wv[u_ + k_];
-            const f32x2 ab_ = (f32x2){xa_ + xb_, xa_ - xb_};
-            sd_[u_] = __builtin_elementwise_fma(csd_, ab_, sd_[u_]);
-            o2_[u_] = fmaf(c2_, ab_.x, o2_[u_]);
-          }
+          for (int u_ = 0; u_ < U; ++u_) pk_t = fmaxf(pk_t, (st * U + u_ < rem) ? m_[u_] : 0.f);
         }
 #pragma unroll
-        for (int u_ = 0; u_ < U; ++u_) m_[u_] = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));
-      } else {
-        float o1_[U];
-#pragma unroll
-        for (int u_ = 0; u_ < U; ++u_) o1_[u_] = 0.f;
-#pragma unroll
-        for (int k_ = 0; k_ < 12; ++k_) {
-          const float c1_ = tpa[k_];
-#pragma unroll
-          for (int u_ = 0; u_ < U; ++u_) o1_[u_] = fmaf(c1_, wv[HX + u_ - k_] + wv[u_ + k_], o1_[u_]);
-        }
-#pragma unroll
-        for (int u_ = 0; u_ < U; ++u_) m_[u_] = fabsf(o1_[u_]);
+        for (int i = 0; i < HX; ++i) wv[i] = wv[i + U];  // (fully unrolled: renamed, not moved)
       }
-      // output frames f0 + u; those at or past the end of the track do not exist
-      const long long f0 = tb + (long long)chunk_of[wave][g * LGD_TP_GROUP + c] * C + st * U;
-      const long long rem = n_frames - f0;
-      const int nv = !need ? 0 : (rem < 0 ? 0 : (rem > U ? U : (int)rem));
-#pragma unroll
-      for (int u_ = 0; u_ < U; ++u_) pk_t = fmaxf(pk_t, (u_ < nv) ? m_[u_] : 0.f);
+      s = s_next;
     }
+  } else {
+    // --------------------------------------------------------------- sparse row
+    // The flagged chunks one after the other, LGD_TP_AHEAD of them in flight: lane j holds frame j (and
+    // j + 64) of the chunk's span [chunk start - HX, + CH) -- contiguous frames, coalesced loads -- and puts
+    // them into LDS, LGD_TP_GROUP chunks at a time; then a lane takes one (chunk, step) slot of the group:
+    // U output frames from U + HX staged ones, evaluated if the adjacent-pair bound of that window (its own
+    // M and S2 now) can still exceed the channel's peak.
+    const bool interior = tb - HX >= 0 && tb + tile_f <= n_frames;  // (wave-uniform) the row's whole span
+    const int n1 = CH - LGD_WAVE;  // frames of the span's second round (C + HX <= 100, C >= 25: may be <= 0)
+    float q0[LGD_TP_AHEAD], q1[LGD_TP_AHEAD];
+    auto fetch_chunk = [&](const int l, float &r0, float &r1) {
+      const long long f = tb + (long long)l * C - HX + lane;  // (l: wave-uniform)
+      if (interior) {
+        const gflt_ptr src = pcm + (tb + (long long)l * C - HX) * nch_tot;
+        const unsigned lo = (unsigned)(lane * nch_tot);
+        r0 = (lane < CH) ? src[lo] : 0.f;
+        r1 = (lane < n1) ? src[lo + (unsigned)(LGD_WAVE * nch_tot)] : 0.f;
+      } else {
+        const bool in0 = lane < CH && f >= 0 && f < n_frames, in1 = lane < n1 && f + LGD_WAVE >= 0 && f + LGD_WAVE < n_frames;
+        r0 = in0 ? pcm[(in0 ? f : 0) * nch_tot] : 0.f;
+        r1 = in1 ? pcm[(in1 ? f + LGD_WAVE : 0) * nch_tot] : 0.f;
+      }
+    };
+    // evaluates the n accepted chunks staged in `buf` (ids in chunk_of)
+    auto run_group = [&](const int n) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // lane slot v = (chunk c of the group, step st): the U output frames c's frames [st U, + U)
+      const int S = n * NSTEP;
+      for (int v0 = 0; v0 < S; v0 += LGD_WAVE) {
+        const int v = v0 + lane;
+        const bool act = v < S;
+        const int vv = act ? v : 0;
+        const int c = (int)(((unsigned)vv * sg.magic_ns) >> 20);
+        const int st = vv - c * NSTEP;
+        const float *w0 = buf + c * CH + st * U;  // frame (st U - HX) of the chunk
+        float wv[U + HX];
+#pragma unroll
+        for (int i = 0; i < U + HX; ++i) wv[i] = w0[i];
+        // adjacent-pair bound of this window: M over all of it, S2 over the pairs the two centre taps of
+        // the U outputs meet
+        float wm = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < U + HX; ++i) wm = fmaxf(wm, fabsf(wv[i]));
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_) s2 = fmaxf(s2, fabsf(wv[PK + u_]) + fabsf(wv[PK + 1 + u_]));
+        const float bound = fmaxf(fmaf(pa2, s2, pb2 * wm), fmaf(pa1, s2, pb1 * wm));
+        const bool need = act && (bound > pthr);
+        if (!__any(need)) continue;  // wave-uniform: nothing in this pass can exceed the final peak
+        float m_[U];
+        fir(wv, m_);
+        // output frames f0 + u; those at or past the end of the track do not exist
+        const long long f0 = tb + (long long)chunk_of[wave][c] * C + st * U;
+        const long long rem = n_frames - f0;
+        const int nv = !need ? 0 : (rem < 0 ? 0 : (rem > U ? U : (int)rem));
+#pragma unroll
+        for (int u_ = 0; u_ < U; ++u_) pk_t = fmaxf(pk_t, (u_ < nv) ? m_[u_] : 0.f);
+      }
+      // (every lane is done with the group before the next one is staged over it)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    unsigned long long todo = mask, ahead = mask;
+#pragma unroll
+    for (int i = 0; i < LGD_TP_AHEAD; ++i) {
+      q0[i] = q1[i] = 0.f;
+      if (ahead) {
+        fetch_chunk(__builtin_ctzll(ahead), q0[i], q1[i]);
+        ahead &= ahead - 1ull;
+      }
+    }
+    int n_acc = 0;
+    while (todo) {
+      const int l = __builtin_ctzll(todo);  // (scalar)
+      todo &= todo - 1ull;
+      const float x0 = q0[0], x1 = q1[0];
+#pragma unroll
+      for (int i = 0; i + 1 < LGD_TP_AHEAD; ++i) { q0[i] = q0[i + 1]; q1[i] = q1[i + 1]; }
+      if (ahead) {
+        fetch_chunk(__builtin_ctzll(ahead), q0[LGD_TP_AHEAD - 1], q1[LGD_TP_AHEAD - 1]);
+        ahead &= ahead - 1ull;
+      }
+      buf[n_acc * CH + lane] = x0;  // (lanes >= CH of the first round spill into the next slot: overwritten or unused)
+      if (lane < n1) buf[n_acc * CH + LGD_WAVE + lane] = x1;
+      if (lane == 0) chunk_of[wave][n_acc] = (unsigned char)l;
+      if (++n_acc == LGD_TP_GROUP) {
+        run_group(n_acc);
+        n_acc = 0;
+      }
+    }
+    if (n_acc) run_group(n_acc);
   }
   const float t = wave_max_f32_uniform(pk_t);
   if (t > 0.f && lane == 0)
     (void)__hip_atomic_fetch_max((unsigned LGD_GLOBAL *)sg.peak_out + nch_tot + chan,
                                  (unsigned)__float_as_int(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }  // rows of this wave
 }
 
 // ------------------------------------------------------- launch wrappers ---
@@ -1099,31 +1301,55 @@ static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg,
   return launch_scan_t<C, 2, 0>(segs, n_seg, nch, s);
 }
 
-// rows_max: most rows (tiles x channels) any segment of the launch has
-extern "C" hipError_t lgd_launch_tp(int chunk, int nch, int tp, const LgdSeg *segs, int n_seg,
-                                    int rows_max, const LgdFilt *F, hipStream_t s) {
+// The kernel instance a chunk length runs on: U = frames per window step (the scan kernel's unroll of that
+// chunk), NS = steps per lane of a dense slab, LP = U NS = 15 / 21 frames: odd (conflict-free LDS stride) and
+// short -- a slab of 64 LP + HX floats is ~4 / 5.5 KB per wave, so the LDS leaves eight waves per SIMD to the
+// latency-bound sparse rows (LP = 25 measured: 26.9 KB per workgroup = 5 per CU, sparse rows 1.6 x slower).
+extern "C" int lgd_tp_instance(int chunk, int *u_out, int *ns_out) {
+  const int u = lgd_unroll(chunk);
+  if (u != 5 && u != 7) return -1;
+  if (u_out) *u_out = u;
+  if (ns_out) *ns_out = 3;
+  return 0;
+}
+
+// One launch for every segment that runs the kernel instance (U, TP, NS), whatever its chunk length and
+// channel count (LgdSeg carries them).  rows_max: most rows (tiles x channels) any of the segments has.
+extern "C" hipError_t lgd_launch_tp(int u, int tp, int ns, const LgdSeg *segs, int n_seg, int rows_max,
+                                    hipStream_t s) {
   if (n_seg <= 0 || rows_max <= 0 || !tp) return hipSuccess;
-  const dim3 grid((unsigned)n_seg, (unsigned)((rows_max + LGD_TP_WAVES - 1) / LGD_TP_WAVES));
+  const dim3 grid((unsigned)n_seg, (unsigned)((rows_max + LGD_TP_WAVES * LGD_TP_RPW - 1) / (LGD_TP_WAVES * LGD_TP_RPW)));
   const dim3 block(LGD_WAVE * LGD_TP_WAVES);
+  if ((long long)rows_max >= (1ll << 26)) return hipErrorInvalidValue;  // (row / nch by umulhi: exact below 2^26)
+#define LGD_TP_CASE(u_, tp_, ns_)                                                         \
+  if (u == u_ && tp == tp_ && ns == ns_) {                                                \
+    hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_>), grid, block, 0, s, segs);           \
+    return hipGetLastError();                                                             \
+  }
+  LGD_TP_CASE(5, 4, 3) LGD_TP_CASE(7, 4, 3) LGD_TP_CASE(5, 2, 3) LGD_TP_CASE(7, 2, 3)
+#undef LGD_TP_CASE
+  return hipErrorInvalidValue;
+}
+
+// the divisions lgd_tp_kernel does by multiplication: checked by the planner per group
+extern "C" int lgd_tp_magics(int chunk, int nch_wg, int tp, unsigned *magic_nch, unsigned *magic_ns, unsigned *magic_c) {
   const int u = lgd_unroll(chunk), hx = tp == 2 ? 23 : 11;
-  const unsigned ch_len = (unsigned)(chunk + hx), nstep = (unsigned)(chunk / u);
-  if (ch_len > LGD_TP_CHMAX) return hipErrorInvalidValue;
-  // x / d == (x * magic) >> 20 over the ranges the kernel divides (checked here, per launch)
-  const unsigned magic_ch = ((1u << 20) + ch_len - 1u) / ch_len, magic_ns = ((1u << 20) + nstep - 1u) / nstep;
-  for (unsigned x = 0; x < LGD_TP_GROUP * ch_len; ++x)
-    if (((x * magic_ch) >> 20) != x / ch_len) return hipErrorInvalidValue;
+  if (chunk + hx > LGD_TP_CHMAX || chunk % u) return -1;  // (a span is at most two rounds of 64 lanes)
+  // frame / chunk == (frame * magic_c) >> 20 for every frame a dense slab can start or end on
+  const unsigned mc = ((1u << 20) + (unsigned)chunk - 1u) / (unsigned)chunk;
+  for (unsigned x = 0; x < (unsigned)(LGD_WAVE * (chunk + 64)); ++x)
+    if (((x * mc) >> 20) != x / (unsigned)chunk) return -1;
+  *magic_c = mc;
+  const unsigned nstep = (unsigned)(chunk / u);
+  // x / d == (x * magic) >> 20 over the range the kernel divides
+  const unsigned mns = ((1u << 20) + nstep - 1u) / nstep;
   for (unsigned x = 0; x < LGD_TP_GROUP * nstep + LGD_WAVE; ++x)
-    if (((x * magic_ns) >> 20) != x / nstep) return hipErrorInvalidValue;
+    if (((x * mns) >> 20) != x / nstep) return -1;
   // row / nch == umulhi(row, magic_nch) for row * (magic_nch * nch - 2^32) < 2^32; the error
   // term is < nch <= 64, so every row below 2^26 divides exactly
-  const unsigned magic_nch = nch == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)nch - 1) / (unsigned)nch);  // 0: k = row
-  if ((long long)rows_max >= (1ll << 26)) return hipErrorInvalidValue;
-  if (u == 5 && tp == 4) hipLaunchKernelGGL((lgd_tp_kernel<5, 4>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns, magic_nch);
-  else if (u == 7 && tp == 4) hipLaunchKernelGGL((lgd_tp_kernel<7, 4>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns, magic_nch);
-  else if (u == 5 && tp == 2) hipLaunchKernelGGL((lgd_tp_kernel<5, 2>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns, magic_nch);
-  else if (u == 7 && tp == 2) hipLaunchKernelGGL((lgd_tp_kernel<7, 2>), grid, block, 0, s, segs, F, chunk, nch, magic_ch, magic_ns, magic_nch);
-  else return hipErrorInvalidValue;
-  return hipGetLastError();
+  *magic_nch = nch_wg == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)nch_wg - 1) / (unsigned)nch_wg);  // 0: k = row
+  *magic_ns = mns;
+  return 0;
 }
 
 // chunk lengths compiled in; the host picks one that divides the rate's s100

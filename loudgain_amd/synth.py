@@ -64,3 +64,36 @@ def adversarial_torch(frames, channels, amplitude=0.8, device="cuda"):
         x[:, c] = tab[(n + c) % 4]
     x.mul_(32768.0).round_().clamp_(-32768, 32767).div_(32768.0)
     return x
+
+
+def limited_torch(frames, channels, rate, seed=0, device="cuda", ceiling=0.8):
+    """Loud, heavily limited programme: Gaussian noise (sigma 0.3) plus a bass and a mid tone through a hard
+    limiter at `ceiling` -- crest factor ~8 dB, thousands of samples per second sit ON the ceiling, so the
+    sample peak is reached everywhere and the true-peak pruning bound (L1 * max|x| of a chunk against the
+    track's sample peak) dismisses next to nothing.  What modern pop masters look like to the scanner."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(0x11A17ED ^ int(seed))
+    x = torch.empty((frames, channels), dtype=torch.float32, device=device)
+    piece = 1 << 24
+    for off in range(0, frames, piece):
+        n = min(piece, frames - off)
+        t = torch.arange(off, off + n, device=device, dtype=torch.float64)
+        blk = torch.randn((n, channels), generator=g, dtype=torch.float32, device=device) * 0.3
+        for c in range(channels):
+            blk[:, c] += (0.15 * torch.sin(2 * np.pi * 110.0 / rate * t + 0.7 * c)
+                          + 0.10 * torch.sin(2 * np.pi * 1870.0 / rate * t + 1.3 * c)).to(torch.float32)
+        x[off:off + n] = blk.clamp_(-ceiling, ceiling)
+    x.mul_(32768.0).round_().clamp_(-32768, 32767).div_(32768.0)
+    return x
+
+
+def limited_numpy(frames, channels, rate, seed=0, ceiling=0.8):
+    """numpy twin of limited_torch (same construction, its own random stream) for the oracle-side tests"""
+    rng = np.random.Generator(np.random.Philox(key=0x11A17ED ^ int(seed)))
+    x = rng.standard_normal((frames, channels), dtype=np.float32) * np.float32(0.3)
+    t = np.arange(frames, dtype=np.float64)
+    for c in range(channels):
+        x[:, c] += (0.15 * np.sin(2 * np.pi * 110.0 / rate * t + 0.7 * c)
+                    + 0.10 * np.sin(2 * np.pi * 1870.0 / rate * t + 1.3 * c)).astype(np.float32)
+    return snap_s16_numpy(np.clip(x, -ceiling, ceiling))

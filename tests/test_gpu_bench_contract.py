@@ -29,7 +29,7 @@ def _check_roofline(rf, algo_bytes):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms_mean"] * 1e-3) / 1e9) / rf["achieved"] < 1e-2
     assert rf["algorithmic_bytes_per_launch"] == algo_bytes
-    assert rf["scan_kernel_only_ms_mean"] <= rf["kernel_ms_mean"] * 1.001
+    assert rf["kernel_ms_min"] <= rf["kernel_ms_mean"] * 1.001
 
 
 def test_bench_line_contract():
@@ -51,6 +51,7 @@ def test_bench_line_contract():
     _check_roofline(c3["roofline"], samples * 4)
     assert c3["peak"] >= d["result"]["peak"]
     assert 0 < c3["adversarial"]["frac"] <= c3["roofline"]["frac"] * 1.05
+    assert 0 < c3["limited"]["frac"] <= c3["roofline"]["frac"] * 1.05 and "f32 interpolator" in c3["dtype"]
     assert d["step_ms"]["min"] <= d["step_ms"]["median"]
     for k in ("f32", "s16"):
         assert d["h2d_inclusive"][k]["msamples_per_s"] > 0

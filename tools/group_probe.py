@@ -13,7 +13,7 @@ for rate, ch in cases:
     nbytes = sum(t.numel() for t in tracks) * 4
     out = []
     for seg in [int(x) for x in os.environ.get("PROBE_SEGS", "0,2,3,4,5,6,8,12").split(",")]:
-        sc = DeviceScanner(0); sc.set_param("overlap", 0)
+        sc = DeviceScanner(0); sc.set_param("overlap", 0); sc.set_param("timing", 2)
         if seg: sc.set_param("seg_subblocks", seg)
         sc.plan(tracks, rate, true_peak=tp and rate < 192000)
         s = torch.cuda.Stream()

@@ -11,7 +11,7 @@ from loudgain_amd.device import DeviceScanner
 rate, ch = 48000, int(os.environ.get("PROBE_CH", 1))
 frames = 172800000 * 2 // ch
 pcm = synth.track_torch(frames, ch, rate, seed=1, device="cuda")
-sc = DeviceScanner(0); sc.set_param("overlap", 0)
+sc = DeviceScanner(0); sc.set_param("overlap", 0); sc.set_param("timing", 2)
 [sc.set_param(k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("PROBE_PARAMS", "").split(",") if kv)]
 sc.plan([pcm], rate, true_peak=True)
 s = torch.cuda.Stream()

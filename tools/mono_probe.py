@@ -10,7 +10,7 @@ for rate, ch in LAYOUTS:
     frames = int(172800000 * 2 / ch)
     pcm = synth.track_torch(frames, ch, rate, seed=1, device="cuda")
     for tp in ORDER:
-        sc = DeviceScanner(0); sc.set_param("overlap", 0); [sc.set_param(k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("PROBE_PARAMS", "").split(",") if kv)]; sc.plan([pcm], rate, true_peak=tp)
+        sc = DeviceScanner(0); sc.set_param("overlap", 0); sc.set_param("timing", 2); [sc.set_param(k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("PROBE_PARAMS", "").split(",") if kv)]; sc.plan([pcm], rate, true_peak=tp)
         s = torch.cuda.Stream()
         for _ in range(N_WARM): sc.execute(s)
         sc.fetch()

@@ -31,6 +31,7 @@ for rate, ch in CASES:
     row = []
     for tp in (False, True):
         sc = DeviceScanner(0)
+        sc.set_param("timing", 2)  # the marker behind the scan kernels (scan_only_*)
         sc.set_param("overlap", 0)
         if a.chunk:
             sc.set_param("chunk", a.chunk)
