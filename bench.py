@@ -54,6 +54,7 @@ def parse_args(argv=None):
                          "sine sampled on its peaks (no true-peak output can be pruned)")
     ap.add_argument("--no-c3", action="store_true", help="c2 on one GPU: skip the c3 object")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer (PCIe-inclusive) figures")
+    ap.add_argument("--no-c4", action="store_true", help="c2 on one GPU: skip the c4 object (the N = 1 anchor of the scaling series)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=int, default=1800, help="audio seconds of the 1-thread CPU leg")
     ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the CPU leg (0 = host cores, <= 16)")
@@ -77,6 +78,10 @@ def parse_args(argv=None):
                     help="every rank uses GPU 0 (needs --backend gloo: RCCL wants one device per rank)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="no GPU work: ranks rendezvous, all-reduce one number, rank 0 prints a JSON line")
+    ap.add_argument("--selftest-die", type=int, default=-1, metavar="RANK",
+                    help="launcher selftest: this rank exits with code 3 after the rendezvous, the others go on into another collective")
+    ap.add_argument("--launch-timeout", type=float, default=540.0,
+                    help="self-launched ranks (--gpus N without a launcher): seconds until the launcher gives up and ends them")
     return ap.parse_args(argv)
 
 
@@ -89,9 +94,13 @@ def free_port():
     return p
 
 
-def launch_children(n, argv):
+def launch_children(n, argv, timeout_s=540.0):
     """`python bench.py --gpus N` without a launcher: N fresh processes, one per GPU.  Nothing in
-    this (parent) process has touched a GPU; it only relays rank 0's line and the exit codes."""
+    this (parent) process has touched a GPU; it only relays rank 0's line and the exit codes.
+    All ranks are watched: the first one that exits non-zero (or the deadline, kept under the
+    driver's own 600 s) ends the others -- a rank that dies after the rendezvous would otherwise
+    leave its peers inside a collective for good -- and the launcher exits non-zero."""
+    import threading
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = []
@@ -99,14 +108,41 @@ def launch_children(n, argv):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r), LGD_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    for ln in out.splitlines():   # stdout carries rank 0's JSON line only (libraries chat on stdout too)
-        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+    out = []
+    reader = threading.Thread(target=lambda: out.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + timeout_s
+    why = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            why = "ranks failed: %s" % bad
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            why = "no result after %.0f s (ranks still running: %s)" % (
+                timeout_s, [r for r, rc in enumerate(rcs) if rc is None])
+            break
+        time.sleep(0.05)
+    if why:  # end exactly the processes started here
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5.0)
+    for ln in out:   # stdout carries rank 0's JSON line only (libraries chat on stdout too)
+        (sys.stdout if ln.startswith("{") and not why else sys.stderr).write(ln if ln.endswith("\n") else ln + "\n")
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+    if why:
+        sys.stderr.write("bench.py: %s\n" % why)
         return 1
     return 0
 
@@ -405,7 +441,7 @@ def main():
     argv = sys.argv[1:]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1 and not os.environ.get("LGD_BENCH_CHILD"):
-        sys.exit(launch_children(args.gpus, argv))   # before anything here touches a GPU
+        sys.exit(launch_children(args.gpus, argv, args.launch_timeout))   # before anything here touches a GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
@@ -419,6 +455,12 @@ def main():
         dist.init_process_group(args.backend, rank=rank, world_size=world)
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t)
+        if args.selftest_die >= 0:
+            if rank == args.selftest_die:
+                os._exit(3)   # dies after the rendezvous ...
+            u = torch.tensor([1.0])
+            dist.all_reduce(u)  # ... while its peers wait for it in the next collective
+            time.sleep(3600)
         if rank == 0:
             print(json.dumps({"launcher_selftest": True, "world_size": dist.get_world_size(),
                               "backend": dist.get_backend(), "sum": float(t.item())}), flush=True)
@@ -495,6 +537,9 @@ def main():
         collective = {"backend": dist.get_backend(),
                       "library": "RCCL (torch.distributed 'nccl' on ROCm)" if dist.get_backend() == "nccl" else "gloo (rehearsal)",
                       "world_size": dist.get_world_size(),
+                      # read back from the gathered records on the device (rank 0's album result of the last step):
+                      # record-1 heads folded in stage 2, how many of them held blocks, records 2 folded in stage 3
+                      "ranks_folded": None,
                       "per_step": "all_gather of album record 1 (%d doubles per rank) + all_gather of record 2 "
                                   "(2 doubles per rank), on a side stream behind the scan" % r1n,
                       "bytes_gathered_per_rank_per_step": 8 * (r1n + 2) * dist.get_world_size()}
@@ -531,6 +576,9 @@ def main():
             line["result"]["album"] = {"loudness": al["loudness"], "lra": al["lra"], "peak": al["peak"],
                                        "n_abs": al["n_abs"], "n_rel": al["n_rel"], "n_st": al["n_st"]}
         if collective:
+            al_ = results[1] if isinstance(results[1], dict) else results[1][0]
+            collective["ranks_folded"] = {"stage2_heads": al_["ranks_stage2"], "with_content": al_["ranks_with_content"],
+                                          "stage3_records": al_["ranks_stage3"]}
             line["collective"] = collective
 
     # one GPU, c2: the reference's own semantics (true peak on) beside it, standard and adversarial material
@@ -571,6 +619,31 @@ def main():
         line["step_ms"] = run.step_times(sc.plan(tracks, rates, true_peak=False, album=False), 20)
         if not args.no_h2d:
             line["h2d_inclusive"] = h2d_inclusive(run, tracks[0], rates[0], True)
+    # one GPU, default line: config 4 too -- the workload `--gpus N` runs for N > 1 -- so that the driver's 1 / 2 / 4 / 8
+    # series has its N = 1 point on the same workload (1000 tracks, 104 GB: fits one GPU's 288 GB)
+    if rank == 0 and world == 1 and workload == "c2" and not args.no_c4 and not distributed and args.workload == "auto":
+        del tracks
+        sc.plan([], [], true_peak=False, album=False)   # (the engine lets go of the C2 buffer)
+        torch.cuda.empty_cache()
+        tr4, rt4 = build_tracks(args, "c4", 0, 1, dev)
+        torch.cuda.synchronize()
+        s4 = sum(int(t.numel()) for t in tr4)
+        ks4 = run.kernel_stats(tr4, rt4, True, True, 8, 3)
+        sc.set_param("overlap", 1 if overlapped else 0)
+        job4 = sc.plan(tr4, rt4, true_peak=True, album=True)
+        steps4 = 20
+        dt4, res4 = run.run(job4, steps4, 3, False)
+        al4 = res4[1] if isinstance(res4[1], dict) else res4[1][0]
+        line["c4"] = {"workload": describe(args, "c4", 1, False), "n_gpus": 1, "scaling": "strong",
+                      "value": round(s4 * steps4 / dt4 / 1e6, 1), "unit": "Msamples/s", "steps": steps4,
+                      "ms_per_step": round(dt4 / steps4 * 1e3, 4), "samples_per_step": s4,
+                      "segments": sc.plan_info()["segments"],
+                      "roofline": roofline_block(s4 * 4, ks4, dt4 / steps4, None, "8 serial launches; pipelined timed region",
+                                                 "lgd_scan_kernel + lgd_peak_reduce_kernel + lgd_tp_kernel"),
+                      "album": {"loudness": al4["loudness"], "lra": al4["lra"], "peak": al4["peak"],
+                                "n_abs": al4["n_abs"], "n_rel": al4["n_rel"], "n_st": al4["n_st"]},
+                      "note": "the N = 1 point of the `--gpus N` series (N > 1 runs this workload, tracks dealt t mod N)"}
+        del tr4, job4, res4
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu

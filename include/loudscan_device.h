@@ -79,6 +79,10 @@ typedef struct {
 typedef struct {
   double loudness, lra, peak, rel_threshold, sum_abs, sum_rel;
   uint64_t n_abs, n_rel, n_st;
+  /* evidence of the exchange, read back from the gathered records on the device: how many ranks' record-1
+   * heads stage 2 folded (1 on a single GPU), how many of them held blocks or a peak of their own, and how
+   * many records 2 stage 3 folded */
+  uint32_t ranks_stage2, ranks_with_content, ranks_stage3, reserved;
 } lgd_album_result;
 
 /* What ranks exchange for an album (one all-gather each, see below).

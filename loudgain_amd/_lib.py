@@ -30,7 +30,9 @@ class LgdTrackResult(C.Structure):
 class LgdAlbumResult(C.Structure):
     _fields_ = [("loudness", C.c_double), ("lra", C.c_double), ("peak", C.c_double),
                 ("rel_threshold", C.c_double), ("sum_abs", C.c_double), ("sum_rel", C.c_double),
-                ("n_abs", C.c_uint64), ("n_rel", C.c_uint64), ("n_st", C.c_uint64)]
+                ("n_abs", C.c_uint64), ("n_rel", C.c_uint64), ("n_st", C.c_uint64),
+                ("ranks_stage2", C.c_uint32), ("ranks_with_content", C.c_uint32), ("ranks_stage3", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

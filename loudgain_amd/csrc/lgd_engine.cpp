@@ -933,7 +933,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     HIPCHK(hipMemset(w.d_rec1, 0, (size_t)c->rec1_len * sizeof(double)));  // the padding stays 0
     w.d_st = w.d_rec1 + 4;
     if ((rc = ensure(&w.d_album, &w.cap_album, (size_t)n_albums * LGD_ALBUM_STRIDE))) return rc;
-    if ((rc = ensure(&w.d_part1, &w.cap_part1, (size_t)n_albums * 4))) return rc;
+    if ((rc = ensure(&w.d_part1, &w.cap_part1, (size_t)n_albums * LGD_PART1))) return rc;
     if ((rc = ensure(&w.d_rec2, &w.cap_rec2, (size_t)n_albums * 2))) return rc;
     if ((rc = ensure(&w.d_heads, &w.cap_heads, (size_t)n_albums * 4))) return rc;
     if ((rc = ensure(&w.d_album_ranges, &w.cap_album_ranges, n_albums))) return rc;
@@ -1252,6 +1252,10 @@ extern "C" int lgd_fetch(lgd_ctx *c, lgd_track_result *out, lgd_album_result *al
       o.n_abs = (uint64_t)a[6];
       o.n_rel = (uint64_t)a[7];
       o.n_st = (uint64_t)a[8];
+      o.ranks_stage2 = (uint32_t)a[9];
+      o.ranks_with_content = (uint32_t)a[10];
+      o.ranks_stage3 = (uint32_t)a[11];
+      o.reserved = 0;
     }
   }
   return LGD_OK;

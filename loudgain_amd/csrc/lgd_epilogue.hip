@@ -814,18 +814,22 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_album_part2_kernel(const doubl
   if (threadIdx.x == 0) {
     rec2[2 * (size_t)blockIdx.x + 0] = sr;
     rec2[2 * (size_t)blockIdx.x + 1] = nr;
-    double sa = 0.0, na = 0.0, pk = 0.0, ns = 0.0;
+    double sa = 0.0, na = 0.0, pk = 0.0, ns = 0.0, live = 0.0;
     for (int r = 0; r < world; ++r) {
       double *h = heads_all + (size_t)r * rec_stride + 4 * (size_t)blockIdx.x;
       sa += h[0]; na += h[1]; pk = fmax(pk, h[2]); ns += h[3];
+      live += (h[1] > 0.0 || h[2] > 0.0) ? 1.0 : 0.0;  // a rank that brought blocks or a peak of its own
       h[0] = 0.0; h[1] = 0.0; h[2] = 0.0; h[3] = 0.0;
     }
-    double *o = part1 + 4 * (size_t)blockIdx.x;
+    double *o = part1 + LGD_PART1 * (size_t)blockIdx.x;
     o[0] = sa; o[1] = na; o[2] = pk; o[3] = ns;
+    o[4] = (double)world;  // heads folded here: what the album result reports as the ranks that took part
+    o[5] = live;
   }
 }
 
-// album[a][] = { loudness, lra (lgd_lra_kernel), peak, thr, sum_abs, sum_rel, n_abs, n_rel, n_st }
+// album[a][] = { loudness, lra (lgd_lra_kernel), peak, thr, sum_abs, sum_rel, n_abs, n_rel, n_st,
+//                heads folded in stage 2, heads with content, records 2 folded }
 // rec2_all: the records 2 of all ranks ([rank][album][2]), summed in rank order
 __global__ void lgd_album_final_kernel(const double *__restrict__ part1_all,
                                        const double *__restrict__ rec2_all, int world, int n_albums,
@@ -833,7 +837,7 @@ __global__ void lgd_album_final_kernel(const double *__restrict__ part1_all,
   LGD_EPI_PRIO();
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_albums) return;
-  const double *part1 = part1_all + 4 * (size_t)a;
+  const double *part1 = part1_all + LGD_PART1 * (size_t)a;
   double *album = album_all + (size_t)a * LGD_ALBUM_STRIDE;
   double thr = 0.0;
   if (part1[1] > 0.0) {
@@ -853,6 +857,9 @@ __global__ void lgd_album_final_kernel(const double *__restrict__ part1_all,
   album[6] = part1[1];
   album[7] = nr;
   album[8] = part1[3];
+  album[9] = part1[4];        // record-1 heads folded in stage 2 (ranks of the exchange)
+  album[10] = part1[5];       // ... of which held blocks or a peak
+  album[11] = (double)world;  // records 2 folded here
 }
 
 // ------------------------------------------------------- launch wrappers ---

@@ -133,7 +133,8 @@ static inline LGD_HD double lgd_channel_weight(int ch, int nch) {
   return 0.0;
 }
 
-#define LGD_ALBUM_STRIDE 16  // doubles per album result record (9 used)
+#define LGD_ALBUM_STRIDE 16  // doubles per album result record (12 used)
+#define LGD_PART1 6          // doubles per folded album head: sum_abs, n_abs, peak, n_st, heads folded, heads with content
 
 // per-track device result: 16 doubles (counts are integer-valued doubles)
 enum {

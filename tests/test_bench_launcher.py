@@ -69,3 +69,24 @@ def test_workload_definitions():
     for world in (1, 2, 3, 8):
         owned = sorted(t for r in range(world) for t in range(r, 1000, world))
         assert owned == list(range(1000))
+
+
+def test_a_rank_that_dies_after_the_rendezvous_ends_the_others():
+    """Rank 1 exits (code 3) once the process group is up; rank 0 then waits for it inside a collective.
+    The launcher has to notice, end rank 0 and exit non-zero -- promptly, not at some outer limit."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--launcher-selftest", "--backend", "gloo", "--selftest-die", "1"])
+    assert r.returncode != 0
+    assert "ranks failed" in r.stderr and "(1, 3)" in r.stderr, r.stderr[-1000:]
+    assert time.time() - t0 < 120
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]   # no result line from a failed run
+
+
+def test_the_launcher_gives_up_at_its_deadline():
+    """Every rank alive but stuck (rank 1 never returns from its sleep): the launcher's own limit ends them."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--launcher-selftest", "--backend", "gloo", "--selftest-die", "7", "--launch-timeout", "20"])
+    assert r.returncode != 0 and "no result after" in r.stderr, r.stderr[-1000:]
+    assert time.time() - t0 < 120

@@ -33,7 +33,8 @@ def _check_roofline(rf, algo_bytes):
 
 
 def test_bench_line_contract():
-    d = _bench("--steps", "30", "--warmup", "3", "--minutes", "2", "--cpu-seconds", "20", "--cpu-procs", "2")
+    d = _bench("--steps", "30", "--warmup", "3", "--minutes", "2", "--cpu-seconds", "20", "--cpu-procs", "2",
+               "--tracks", "40", "--track-scale", "0.05")
     assert d["metric"].startswith("Msamples/s scanned") and d["unit"] == "Msamples/s"
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 3
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -53,6 +54,12 @@ def test_bench_line_contract():
     assert 0 < c3["adversarial"]["frac"] <= c3["roofline"]["frac"] * 1.05
     assert 0 < c3["limited"]["frac"] <= c3["roofline"]["frac"] * 1.05 and "f32 interpolator" in c3["dtype"]
     assert d["step_ms"]["min"] <= d["step_ms"]["median"]
+    # the N = 1 anchor of the scaling series: config 4 (here 40 short tracks) on the same line
+    c4 = d["c4"]
+    assert c4["workload"].startswith("C4") and c4["scaling"] == "strong" and c4["n_gpus"] == 1 and c4["value"] > 0
+    assert abs(c4["value"] - c4["samples_per_step"] / (c4["ms_per_step"] * 1e-3) / 1e6) / c4["value"] < 1e-3
+    _check_roofline(c4["roofline"], c4["samples_per_step"] * 4)
+    assert c4["album"]["n_abs"] > 0
     for k in ("f32", "s16"):
         assert d["h2d_inclusive"][k]["msamples_per_s"] > 0
     cb = d["cpu_baseline"]
