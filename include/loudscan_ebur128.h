@@ -20,8 +20,9 @@
  * plus ebur128_add_frames_float and ebur128_sample_peak (same machinery).
  *
  * How it differs from the CPU library: frames are only collected by
- * ebur128_add_frames_*; the arithmetic runs on the GPU at the first query (one batched
- * launch per state, one per _multiple call) and is cached until more frames arrive.
+ * ebur128_add_frames_*; the arithmetic runs on the GPU at the first query -- ONE batched scan
+ * of every live state that holds frames, as the tracks of one album -- and every later query
+ * of those states, single or _multiple, is served from its results until more frames arrive.
  * Momentary / short-term queries, ebur128_set_channel and the histogram mode are not
  * provided (loudgain does not use them).  There is no CPU fallback: without a HIP
  * device ebur128_init returns NULL.
@@ -83,6 +84,9 @@ int ebur128_true_peak(ebur128_state *st, unsigned int channel_number, double *ou
 
 /* extension: GPU used by states created afterwards (default 0) */
 int loudscan_ebur128_set_device(int device);
+/* extension: scans (plans) run so far in this process.  A session driven the way loudgain's main drives
+ * scan.c (loudgain.c:299-340: every file scanned, then every result queried) costs exactly one. */
+unsigned long long loudscan_ebur128_plan_count(void);
 
 #ifdef __cplusplus
 }

@@ -35,13 +35,14 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
                                                 const LgdTrackMeta *meta, int n_tracks,
                                                 const double *E, double *Z, double *st,
                                                 const float *peaks, double *p1, double *p2,
-                                                double *pmax_s, double *res, double abs_gate,
-                                                double rel_factor, int do_tp, hipStream_t s);
+                                                double *pmax_s, double *res, unsigned *done_count,
+                                                double abs_gate, double rel_factor, double minus20, int do_tp,
+                                                int skip_big, hipStream_t s);
 extern "C" size_t lgd_lra_pick_bytes(void);
 extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
                                      double minus20, const int *big_idx, int n_big, unsigned *hist,
                                      double *part, void *picks, double *cand, const long long *cand_off,
-                                     hipStream_t s);
+                                     int small_too, hipStream_t s);
 extern "C" hipError_t lgd_launch_album_part1(const double *res, const LgdAlbumMeta *albums,
                                              int n_albums, double *heads, hipStream_t s);
 extern "C" hipError_t lgd_launch_album_stage2(const LgdSlice *slices, int n_slices,
@@ -316,6 +317,8 @@ struct lgd_ctx {
   struct WorkSet {
     double *d_E = nullptr, *d_Z = nullptr, *d_st = nullptr, *d_res = nullptr, *d_album = nullptr;
     double *d_p1 = nullptr, *d_p2 = nullptr, *d_p2a = nullptr, *d_pmax = nullptr;  // per-slice partials
+    unsigned *d_done = nullptr;  // per track: epilogue workgroups finished (lgd_track_epilogue_kernel)
+    size_t cap_done = 0;
     // album: record 1 = {sum_abs, n_abs, peak, n_st | st energies | 0-padding}, record 2 =
     // {sum_rel, n_rel} are what ranks exchange; d_st points into record 1; part1 = folded heads
     // (single-GPU plans may hold many albums: heads / part1 / rec2 / album are per album)
@@ -414,13 +417,20 @@ extern "C" lgd_ctx *lgd_create(int device) {
     ok = ok && hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&w.ev_album, hipEventDisableTiming) == hipSuccess;
   }
-  ok = ok && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+  // HIP deals a process's streams over a few hardware queues (four by default) and streams that share a queue run
+  // one after the other: with three more streams per context the caller's stream and `side` once ended up on one
+  // queue and "overlap" 1 no longer overlapped (0.285 -> 0.317 ms per step).  Queues are kept per priority level, so
+  // the internal stream asks for the highest one -- a queue the caller's (normal) stream cannot be on -- and the group
+  // streams are created only when a plan asks for them.
+  {
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    ok = ok && hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_high) == hipSuccess;
+  }
   ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; i < lgd_ctx::GSTREAMS; ++i) {
-    ok = ok && hipStreamCreateWithFlags(&c->gstream[i], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < lgd_ctx::GSTREAMS; ++i)
     ok = ok && hipEventCreateWithFlags(&c->ev_gjoin[i], hipEventDisableTiming) == hipSuccess;
-  }
   ok = ok && hipMalloc((void **)&c->d_filt, MAX_GROUPS * sizeof(LgdFilt)) == hipSuccess;
   if (!ok) {
     fail(LGD_ENOMEM, "lgd_create: allocation failed");
@@ -435,7 +445,7 @@ extern "C" void lgd_destroy(lgd_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (auto &w : c->ws) {
-    void *ptrs[] = {w.d_E, w.d_Z, w.d_rec1, w.d_res, w.d_album, w.d_part1, w.d_rec2, w.d_peaks,
+    void *ptrs[] = {w.d_E, w.d_Z, w.d_rec1, w.d_res, w.d_album, w.d_part1, w.d_rec2, w.d_peaks, w.d_done,
                     w.d_segs, w.d_segs_tp, w.d_ranges, w.d_album_range, w.d_p1, w.d_p2, w.d_p2a, w.d_heads,
                     w.d_album_ranges, w.d_pmax, w.d_hint, w.d_tp_rows, w.d_big_tr, w.d_big_al, w.d_big_one,
                     w.d_off_tr, w.d_off_al, w.d_off_one, w.d_lra_hist, w.d_lra_part, w.d_lra_cand, w.d_lra_picks};
@@ -475,7 +485,7 @@ extern "C" int lgd_set_param(lgd_ctx *c, const char *name, long value) {
   else if (!strcmp(name, "album_slots")) c->p_album_slots = value;  // short-term slots of album record 1
   else if (!strcmp(name, "tp_prune")) c->p_tp_prune = value;  // 0: evaluate every interpolator window
   else if (!strcmp(name, "tp_dense_min")) c->p_tp_dense_min = value;  // rows with >= this many flagged chunks (of 64) are walked whole; 65 = never
-  else if (!strcmp(name, "group_streams")) { c->p_group_streams = value; return LGD_OK; }  // 0: groups one after the other
+  else if (!strcmp(name, "group_streams")) c->p_group_streams = value;  // 0: groups one after the other
   else if (!strcmp(name, "merge_launches")) c->p_merge = value;  // 1: groups that share a kernel instance go out in one launch
   else if (!strcmp(name, "strided")) c->p_strided = value;  // channel pair / triple workgroups: 0 never, 1 where measured faster, 2 pairs for every 3+ channel layout, 3 triples wherever the count divides
   else if (!strcmp(name, "album_world")) c->p_album_world = value ? value : 8;  // ranks the multi-GPU album scratch is sized for
@@ -582,7 +592,9 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     m.e_off = (long long)c->total_e;
     m.st_off = (long long)c->total_st;
     m.slice_off = (int)c->slices.size();
-    m.n_slices = m.n_sb >= 4 ? (m.n_sb - 3 + LGD_SLICE - 1) / LGD_SLICE : 0;
+    // (at least one: the track's last epilogue workgroup writes its result record -- a track shorter than
+    // 400 ms has one slice without blocks)
+    m.n_slices = m.n_sb >= 4 ? (m.n_sb - 3 + LGD_SLICE - 1) / LGD_SLICE : 1;
     for (int sl = 0; sl < m.n_slices; ++sl) c->slices.push_back(LgdSlice{(int)t, sl * LGD_SLICE});
     c->total_sb += nsb;
     c->total_e += nsb * tr.channels;
@@ -907,6 +919,9 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
 
   HIPCHK(hipDeviceSynchronize());  // nothing of an older plan may still be running
   c->n_sets = c->p_overlap ? ((flags & LGD_FLAG_ALBUM_PART1) ? 4 : 2) : 1;
+  if (c->p_group_streams)
+    for (int i = 0; i < lgd_ctx::GSTREAMS; ++i)
+      if (!c->gstream[i]) HIPCHK(hipStreamCreateWithFlags(&c->gstream[i], hipStreamNonBlocking));
   if (c->p_album_slots && (uint64_t)c->p_album_slots < c->total_st)
     return fail(LGD_EINVAL, "album_slots %ld < the %llu short-term slots of this plan", c->p_album_slots,
                 (unsigned long long)c->total_st);
@@ -929,6 +944,8 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if ((rc = ensure(&w.d_p2, &w.cap_p2, 2 * c->slices.size()))) return rc;
     if ((rc = ensure(&w.d_p2a, &w.cap_p2a, 2 * c->slices.size()))) return rc;
     if ((rc = ensure(&w.d_pmax, &w.cap_pmax, c->slices.size()))) return rc;
+    if ((rc = ensure(&w.d_done, &w.cap_done, n))) return rc;
+    HIPCHK(hipMemset(w.d_done, 0, (n ? n : 1) * sizeof(unsigned)));
     if ((rc = ensure(&w.d_rec1, &w.cap_rec1, (size_t)c->rec1_len))) return rc;
     HIPCHK(hipMemset(w.d_rec1, 0, (size_t)c->rec1_len * sizeof(double)));  // the padding stays 0
     w.d_st = w.d_rec1 + 4;
@@ -1064,10 +1081,10 @@ static int album_stage3_on(lgd_ctx *c, lgd_ctx::WorkSet &w, const double *all2, 
     HIPCHK(hipMemcpyAsync(w.d_album_range, w.h_album_range, sizeof(LgdRange), hipMemcpyHostToDevice, s));
     const int big = (w.lra_n > LGD_LRA_BIG && w.lra_n <= w.lra_dist_cap) ? 1 : 0;
     HIPCHK(lgd_launch_lra(w.d_album_range, 1, w.lra_base, c->minus20, w.d_big_one, big, w.d_lra_hist,
-                          w.d_lra_part, w.d_lra_picks, w.d_lra_cand, w.d_off_one, s));
+                          w.d_lra_part, w.d_lra_picks, w.d_lra_cand, w.d_off_one, 1, s));
   } else {
     HIPCHK(lgd_launch_lra(w.d_album_ranges, n_albums, w.d_st, c->minus20, w.d_big_al, w.n_big_al,
-                          w.d_lra_hist, w.d_lra_part, w.d_lra_picks, w.d_lra_cand, w.d_off_al, s));
+                          w.d_lra_hist, w.d_lra_part, w.d_lra_picks, w.d_lra_cand, w.d_off_al, 1, s));
   }
   return LGD_OK;
 }
@@ -1122,6 +1139,12 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   // next scan's workgroups fill the GPU as the previous scan's drain, and its small
   // gating / LRA kernels run beside the following scan -- no event packets between
   // the dominant kernels.  Results are defined after lgd_fetch (which joins both).
+  // (Measured and dropped, round 3: scans alternating between two internal streams with every epilogue on a third
+  // one, four work sets -- 0.282 ms per step against 0.285 for this form when all streams sat on hardware queues
+  // of their own, 0.309 when two of them shared one: HIP deals a process's streams over four hardware queues, and
+  // which stream lands where is not ours to choose.  What this form really does: scan k + 1, on the internal
+  // stream, waits for everything enqueued before it on the caller's stream, i.e. for epilogue k - 1, and scan
+  // k + 2 follows that epilogue too -- scans run in pairs that share the GPU, then their two epilogues.)
   hipStream_t s = caller;
   if (c->n_sets >= 2 && (k & 1)) {
     s = c->side;
@@ -1142,7 +1165,7 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   // CUs badly, and every cross-stream dependency costs its latency), hence off by default; every
   // group is sized to fill the GPU by itself instead (see the segment lengths in lgd_plan).
   const size_t ng = c->launches.size();
-  const int n_side = (c->p_group_streams && ng > 1) ? (int)std::min<size_t>(ng - 1, lgd_ctx::GSTREAMS) : 0;
+  const int n_side = (c->p_group_streams && ng > 1 && c->gstream[0]) ? (int)std::min<size_t>(ng - 1, lgd_ctx::GSTREAMS) : 0;
   if (n_side) {
     HIPCHK(hipEventRecord(c->ev_fork, s));
     for (int i = 0; i < n_side; ++i) HIPCHK(hipStreamWaitEvent(c->gstream[i], c->ev_fork, 0));
@@ -1173,11 +1196,15 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
     for (const TpLaunch &T : c->tp_launches)
       HIPCHK(lgd_launch_tp(T.u, T.tp, T.ns, w.d_segs_tp + T.seg_begin, (int)T.seg_count, T.rows_max, s));
   if (c->p_timing) HIPCHK(hipEventRecord(ev[1], s));
+  // gating pass 1, pass 2, result records and loudness ranges of all tracks: one launch (the long short-term
+  // lists, > LGD_LRA_BIG entries, through the multi-workgroup kernels behind it)
   HIPCHK(lgd_launch_track_epilogue(c->d_slices, (int)c->slices.size(), c->d_meta, n, w.d_E, w.d_Z,
-                                   w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_pmax, w.d_res, c->abs_gate,
-                                   c->rel_factor, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0, s));
-  HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, w.d_big_tr, w.n_big_tr, w.d_lra_hist,
-                        w.d_lra_part, w.d_lra_picks, w.d_lra_cand, w.d_off_tr, s));
+                                   w.d_st, w.d_peaks, w.d_p1, w.d_p2, w.d_pmax, w.d_res, w.d_done, c->abs_gate,
+                                   c->rel_factor, c->minus20, (c->flags & LGD_FLAG_TRUE_PEAK) ? 1 : 0,
+                                   w.n_big_tr > 0 ? 1 : 0, s));
+  if (w.n_big_tr > 0)
+    HIPCHK(lgd_launch_lra(w.d_ranges, n, w.d_st, c->minus20, w.d_big_tr, w.n_big_tr, w.d_lra_hist,
+                          w.d_lra_part, w.d_lra_picks, w.d_lra_cand, w.d_off_tr, 0, s));
   c->executed = true;
   if (c->flags & (LGD_FLAG_ALBUM | LGD_FLAG_ALBUM_PART1))
     HIPCHK(lgd_launch_album_part1(w.d_res, c->d_albums, (int)c->albums.size(),

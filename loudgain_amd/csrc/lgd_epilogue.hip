@@ -62,13 +62,24 @@ __device__ __forceinline__ double energy_to_loudness(double e) {
 
 // ---- pass 1: 400 ms block energies (E5), 3 s block energies (E6), absolute gate
 // p1[slice] = { n_abs, sum_abs, n_st, max 400 ms energy }; pmax_s[slice] = max 3 s energy on
-// the 100 ms grid (windows ending inside the slice)
+// the 100 ms grid (windows ending inside the slice).
+// (LGD_P1_LDS 1 stages the slice's sub-block energies in LDS first, one plane per weighted channel: measured no
+// faster -- 13.6 us against 14 us for the 36 slices of C2's one-hour track, the kernel is a chain of a few
+// dependent latencies either way -- and its 43 KB per workgroup do not fit beside the next scan's four
+// workgroups per CU when scans pipeline: off.)
+#ifndef LGD_P1_LDS
+#define LGD_P1_LDS 0
+#endif
+#define LGD_P1_SPAN (LGD_SLICE + 40)  // sub-blocks a slice's blocks and windows reach: [j0, j0 + 1024 + 38)
 __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
     const LgdSlice *__restrict__ slices, const LgdTrackMeta *__restrict__ meta,
     const double *__restrict__ E_all, double *__restrict__ Z_all, double *__restrict__ st_all,
     double *__restrict__ p1, double *__restrict__ pmax_s, double abs_gate) {
   LGD_EPI_PRIO();
   __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
+#if LGD_P1_LDS
+  __shared__ double Es[5][LGD_P1_SPAN];
+#endif
   const LgdSlice sl = slices[blockIdx.x];
   const LgdTrackMeta m = meta[sl.track];
   const double *E = E_all + m.e_off;  // channel ch, sub-block j at E[ch * n_sb + j]
@@ -76,19 +87,37 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
   const int tid = threadIdx.x;
   const int nblk = m.n_sb - 3;
   const int j1 = min(sl.j0 + LGD_SLICE, nblk);
+  // channels mapped EBUR128_UNUSED (weight 0) are skipped like the reference does
+  int wch[5];
+  double wgt[5];
+  int nw = 0;
+  for (int ch = 0; ch < m.nch && nw < 5; ++ch) {
+    const double w = lgd_channel_weight(ch, m.nch);
+    if (w != 0.0) { wch[nw] = ch; wgt[nw] = w; ++nw; }
+  }
+#if LGD_P1_LDS
+  for (int c = 0; c < nw; ++c) {
+    const double *Ec = E + (size_t)wch[c] * m.n_sb;
+    for (int i = tid; i < LGD_P1_SPAN; i += LGD_EPI_NT) {
+      const int j = sl.j0 + i;
+      Es[c][i] = j < m.n_sb ? Ec[j] : 0.0;
+    }
+  }
+  __syncthreads();
+#define LGD_P1_E(c_, j_) (Es[c_] + ((j_) - sl.j0))
+#else
+#define LGD_P1_E(c_, j_) (E + (size_t)wch[c_] * m.n_sb + (j_))
+#endif
   // divide like the reference does (sum /= frames_per_block), not by a reciprocal
   const double len4 = 4.0 * (double)m.s100, len30 = 30.0 * (double)m.s100;
   double cnt = 0.0, sum = 0.0, cst = 0.0, zmax = 0.0, smax = 0.0;
-  // block energy = sum_c w_c * (channel sum over the block) / frames (A.4);
-  // channels mapped EBUR128_UNUSED (weight 0) are skipped like the reference does
+  // block energy = sum_c w_c * (channel sum over the block) / frames (A.4)
   for (int j = sl.j0 + tid; j < j1; j += LGD_EPI_NT) {
     double s = 0.0;
-    for (int ch = 0; ch < m.nch; ++ch) {
-      const double w = lgd_channel_weight(ch, m.nch);
-      if (w == 0.0) continue;
-      const double *Ec = E + (size_t)ch * m.n_sb + j;
+    for (int c = 0; c < nw; ++c) {
+      const double *Ec = LGD_P1_E(c, j);
       double cs = ((Ec[0] + Ec[1]) + Ec[2]) + Ec[3];
-      if (w != 1.0) cs *= w;
+      if (wgt[c] != 1.0) cs *= wgt[c];
       s += cs;
     }
     const double zj = s / len4;
@@ -97,17 +126,15 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
     if (zj >= abs_gate) { cnt += 1.0; sum += zj; }
   }
   // largest 3 s energy on the 100 ms grid: window jj covers sub-blocks [jj, jj + 30); the
-  // running sum per thread is rebuilt every hop from the 30 values (exact, order-fixed)
+  // sum per window is rebuilt every hop from the 30 values (exact, order-fixed)
   for (int jj = sl.j0 + tid; jj < min(sl.j0 + LGD_SLICE, m.n_sb - 29); jj += LGD_EPI_NT) {
     double s = 0.0;
-    for (int ch = 0; ch < m.nch; ++ch) {
-      const double w = lgd_channel_weight(ch, m.nch);
-      if (w == 0.0) continue;
-      const double *p = E + (size_t)ch * m.n_sb + jj;
+    for (int c = 0; c < nw; ++c) {
+      const double *p = LGD_P1_E(c, jj);
       double cs = 0.0;
 #pragma unroll 6
       for (int i = 0; i < 30; ++i) cs += p[i];
-      if (w != 1.0) cs *= w;
+      if (wgt[c] != 1.0) cs *= wgt[c];
       s += cs;
     }
     smax = fmax(smax, s / len30);
@@ -117,14 +144,12 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass1(
   const int k0 = (sl.j0 + 9) / 10, k1 = min((sl.j0 + LGD_SLICE + 9) / 10, m.n_st_slots);
   for (int kk = k0 + tid; kk < k1; kk += LGD_EPI_NT) {
     double s = 0.0;
-    for (int ch = 0; ch < m.nch; ++ch) {
-      const double w = lgd_channel_weight(ch, m.nch);
-      if (w == 0.0) continue;
-      const double *p = E + (size_t)ch * m.n_sb + 10 * kk;
+    for (int c = 0; c < nw; ++c) {
+      const double *p = LGD_P1_E(c, 10 * kk);
       double cs = 0.0;
 #pragma unroll 6
       for (int i = 0; i < 30; ++i) cs += p[i];
-      if (w != 1.0) cs *= w;
+      if (wgt[c] != 1.0) cs *= wgt[c];
       s += cs;
     }
     s /= len30;
@@ -194,69 +219,6 @@ __global__ __launch_bounds__(LGD_EPI_NT) void lgd_gate_pass2(
   if (tid == 0) {
     p2[2 * (size_t)blockIdx.x + 0] = cnt;
     p2[2 * (size_t)blockIdx.x + 1] = sum;
-  }
-}
-
-// ---- per-track result record (E7 loudness, E9 peaks, counts) ----------------
-__global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_final(
-    const LgdTrackMeta *__restrict__ meta, const double *__restrict__ p1,
-    const double *__restrict__ p2, const double *__restrict__ pmax_s,
-    const float *__restrict__ peaks, double *__restrict__ res_all, double rel_factor, int do_tp) {
-  LGD_EPI_PRIO();
-  __shared__ double sh[LGD_EPI_NT / LGD_WAVE];
-  const LgdTrackMeta m = meta[blockIdx.x];
-  double *res = res_all + (size_t)blockIdx.x * LGR_STRIDE;
-  const int tid = threadIdx.x;
-  double a = 0.0, b = 0.0, c = 0.0, d = 0.0, e = 0.0, mm = 0.0, ms = 0.0;
-  for (int i = tid; i < m.n_slices; i += LGD_EPI_NT) {
-    const size_t s = (size_t)(m.slice_off + i);
-    a += p1[4 * s + 0];
-    b += p1[4 * s + 1];
-    c += p1[4 * s + 2];
-    mm = fmax(mm, p1[4 * s + 3]);
-    ms = fmax(ms, pmax_s[s]);
-    d += p2[2 * s + 0];
-    e += p2[2 * s + 1];
-  }
-  mm = block_max_f64<LGD_EPI_NT>(mm, sh);
-  ms = block_max_f64<LGD_EPI_NT>(ms, sh);
-  const double n_abs = block_sum_f64<LGD_EPI_NT>(a, sh);
-  const double sum_abs = block_sum_f64<LGD_EPI_NT>(b, sh);
-  const double n_st = block_sum_f64<LGD_EPI_NT>(c, sh);
-  const double n_rel = block_sum_f64<LGD_EPI_NT>(d, sh);
-  const double sum_rel = block_sum_f64<LGD_EPI_NT>(e, sh);
-  double sp = 0.0, tp = 0.0;
-  for (int i = tid; i < m.n_seg * m.nch; i += LGD_EPI_NT) {
-    const int sgi = i / m.nch, ch = i % m.nch;
-    const float *pp = peaks + m.peak_off + (size_t)sgi * 2 * m.nch;
-    sp = fmax(sp, (double)pp[ch]);
-    tp = fmax(tp, (double)pp[m.nch + ch]);
-  }
-  sp = block_max_f64<LGD_EPI_NT>(sp, sh);
-  tp = block_max_f64<LGD_EPI_NT>(tp, sh);
-  if (tid == 0) {
-    double thr = 0.0;
-    if (n_abs > 0.0) {
-      thr = sum_abs / n_abs;
-      thr *= rel_factor;
-    }
-    res[LGR_LOUDNESS] = n_rel > 0.0 ? energy_to_loudness(sum_rel / n_rel) : -HUGE_VAL;
-    res[LGR_MAX_M] = mm > 0.0 ? energy_to_loudness(mm) : -HUGE_VAL;
-    res[LGR_MAX_S] = ms > 0.0 ? energy_to_loudness(ms) : -HUGE_VAL;
-    res[LGR_PEAK] = do_tp ? fmax(sp, tp) : sp;
-    res[LGR_SPEAK] = sp;
-    // ebur128_true_peak's value: max(interpolated, sample).  (The scan kernel evaluates only
-    // the interpolator outputs that can exceed the track's sample peak, so the interpolated
-    // maximum alone is exact only where it is the larger of the two.)
-    res[LGR_TPEAK] = do_tp ? fmax(sp, tp) : 0.0;
-    res[LGR_THR] = thr;
-    res[LGR_SUM_ABS] = sum_abs;
-    res[LGR_SUM_REL] = sum_rel;
-    res[LGR_NBLK] = (double)(m.n_sb >= 4 ? m.n_sb - 3 : 0);
-    res[LGR_NABS] = n_abs;
-    res[LGR_NREL] = n_rel;
-    res[LGR_NSTBLK] = (double)m.n_st_slots;
-    res[LGR_NST] = n_st;
   }
 }
 
@@ -499,6 +461,126 @@ __global__ __launch_bounds__(LGD_LRA_NT) void lgd_lra_kernel(const LgdRange *__r
   else if (n <= 8 * LGD_LRA_NT) lgd_lra_in_registers<8>(gv, n, minus20, rg.out, S);
   else if (n <= 16 * LGD_LRA_NT) lgd_lra_in_registers<16>(gv, n, minus20, rg.out, S);
   else lgd_lra_in_registers<LGD_LRA_RMAX>(gv, n, minus20, rg.out, S);
+}
+
+// ---- everything behind pass 1 in ONE launch (round 2: lgd_gate_pass2, lgd_track_final, lgd_lra_kernel -- three
+// dependent launches of a few workgroups each behind every scan).  Workgroups [0, n_slices): pass 2 of one slice
+// (E7: blocks at or above both gates); the LAST of a track's slices to finish (a counter per track, release /
+// acquire fences at device scope) writes the track's result record (E7 loudness, E9 peaks, counts).
+// Workgroups [n_slices, n_slices + n_tracks): the loudness range of one track's short-term list (E8) -- it only
+// depends on pass 1, so it runs beside pass 2 instead of behind it (lists longer than LGD_LRA_BIG: the
+// lgd_lra_big_* launches).
+__global__ __launch_bounds__(LGD_EPI_NT) void lgd_track_finish_kernel(
+    const LgdSlice *__restrict__ slices, int n_slices, const LgdTrackMeta *__restrict__ meta,
+    const double *__restrict__ Z_all, const double *__restrict__ st_all, const float *__restrict__ peaks,
+    const double *__restrict__ p1, double *__restrict__ p2, const double *__restrict__ pmax_s,
+    double *__restrict__ res_all, unsigned *__restrict__ done_count, double abs_gate, double rel_factor,
+    double minus20, int do_tp, int skip_big) {
+  LGD_EPI_PRIO();
+  __shared__ LgdLraShared S;
+  __shared__ int s_last;
+  double *sh = S.sh;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= n_slices) {  // ---- E8: one track's loudness range
+    const int track = (int)blockIdx.x - n_slices;
+    const LgdTrackMeta m = meta[track];
+    const double *gv = st_all + m.st_off;
+    const int n = m.n_st_slots;
+    double *out = res_all + (size_t)track * LGR_STRIDE + LGR_LRA;
+    if (n > LGD_LRA_BIG) {
+      if (!skip_big) lgd_lra_streaming(gv, n, minus20, out, S);
+      return;
+    }
+    if (n <= 1 * LGD_LRA_NT) lgd_lra_in_registers<1>(gv, n, minus20, out, S);
+    else if (n <= 2 * LGD_LRA_NT) lgd_lra_in_registers<2>(gv, n, minus20, out, S);
+    else if (n <= 4 * LGD_LRA_NT) lgd_lra_in_registers<4>(gv, n, minus20, out, S);
+    else if (n <= 8 * LGD_LRA_NT) lgd_lra_in_registers<8>(gv, n, minus20, out, S);
+    else if (n <= 16 * LGD_LRA_NT) lgd_lra_in_registers<16>(gv, n, minus20, out, S);
+    else lgd_lra_in_registers<LGD_LRA_RMAX>(gv, n, minus20, out, S);
+    return;
+  }
+  // ---- pass 2 of one slice; thr from the track's own pass-1 totals (strided per-thread partials, fixed trees)
+  const LgdSlice sl = slices[blockIdx.x];
+  const LgdTrackMeta m = meta[sl.track];
+  const double *Z = Z_all + m.sb_off;
+  const int j1 = min(sl.j0 + LGD_SLICE, m.n_sb - 3);
+  double a = 0.0, b = 0.0, c = 0.0, mm = 0.0, ms = 0.0;
+  for (int i = tid; i < m.n_slices; i += LGD_EPI_NT) {
+    const size_t s = (size_t)(m.slice_off + i);
+    a += p1[4 * s + 0];
+    b += p1[4 * s + 1];
+    c += p1[4 * s + 2];
+    mm = fmax(mm, p1[4 * s + 3]);
+    ms = fmax(ms, pmax_s[s]);
+  }
+  const double n_abs = block_sum_f64<LGD_EPI_NT>(a, sh);
+  const double sum_abs = block_sum_f64<LGD_EPI_NT>(b, sh);
+  double thr = 0.0;
+  if (n_abs > 0.0) {
+    thr = sum_abs / n_abs;
+    thr *= rel_factor;
+  }
+  double cnt = 0.0, sum = 0.0;
+  for (int j = sl.j0 + tid; j < j1; j += LGD_EPI_NT) {
+    const double zj = Z[j];
+    if (zj >= abs_gate && zj >= thr) { cnt += 1.0; sum += zj; }
+  }
+  cnt = block_sum_f64<LGD_EPI_NT>(cnt, sh);
+  sum = block_sum_f64<LGD_EPI_NT>(sum, sh);
+  if (tid == 0) {
+    p2[2 * (size_t)blockIdx.x + 0] = cnt;
+    p2[2 * (size_t)blockIdx.x + 1] = sum;
+    // this slice's partials before the count; the other slices' after the count has been seen
+    __threadfence();
+    const unsigned old = __hip_atomic_fetch_add(&done_count[sl.track], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old + 1u == (unsigned)m.n_slices;
+    if (s_last) done_count[sl.track] = 0u;  // ready for the next scan into this work set
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // ---- the track's result record
+  double *res = res_all + (size_t)sl.track * LGR_STRIDE;
+  mm = block_max_f64<LGD_EPI_NT>(mm, sh);
+  ms = block_max_f64<LGD_EPI_NT>(ms, sh);
+  const double n_st = block_sum_f64<LGD_EPI_NT>(c, sh);
+  double d = 0.0, e = 0.0;
+  const volatile double *p2v = p2;  // (written by other workgroups during this launch: no cached copies)
+  for (int i = tid; i < m.n_slices; i += LGD_EPI_NT) {
+    const size_t s = (size_t)(m.slice_off + i);
+    d += p2v[2 * s + 0];
+    e += p2v[2 * s + 1];
+  }
+  const double n_rel = block_sum_f64<LGD_EPI_NT>(d, sh);
+  const double sum_rel = block_sum_f64<LGD_EPI_NT>(e, sh);
+  double sp = 0.0, tp = 0.0;
+  for (int i = tid; i < m.n_seg * m.nch; i += LGD_EPI_NT) {
+    const int sgi = i / m.nch, ch = i % m.nch;
+    const float *pp = peaks + m.peak_off + (size_t)sgi * 2 * m.nch;
+    sp = fmax(sp, (double)pp[ch]);
+    tp = fmax(tp, (double)pp[m.nch + ch]);
+  }
+  sp = block_max_f64<LGD_EPI_NT>(sp, sh);
+  tp = block_max_f64<LGD_EPI_NT>(tp, sh);
+  if (tid == 0) {
+    res[LGR_LOUDNESS] = n_rel > 0.0 ? energy_to_loudness(sum_rel / n_rel) : -HUGE_VAL;
+    res[LGR_MAX_M] = mm > 0.0 ? energy_to_loudness(mm) : -HUGE_VAL;
+    res[LGR_MAX_S] = ms > 0.0 ? energy_to_loudness(ms) : -HUGE_VAL;
+    res[LGR_PEAK] = do_tp ? fmax(sp, tp) : sp;
+    res[LGR_SPEAK] = sp;
+    // ebur128_true_peak's value: max(interpolated, sample).  (The true-peak kernel evaluates only
+    // the interpolator outputs that can exceed the track's sample peak, so the interpolated
+    // maximum alone is exact only where it is the larger of the two.)
+    res[LGR_TPEAK] = do_tp ? fmax(sp, tp) : 0.0;
+    res[LGR_THR] = thr;
+    res[LGR_SUM_ABS] = sum_abs;
+    res[LGR_SUM_REL] = sum_rel;
+    res[LGR_NBLK] = (double)(m.n_sb >= 4 ? m.n_sb - 3 : 0);
+    res[LGR_NABS] = n_abs;
+    res[LGR_NREL] = n_rel;
+    res[LGR_NSTBLK] = (double)m.n_st_slots;
+    res[LGR_NST] = n_st;
+  }
 }
 
 // ---- E8 for LONG lists (an album of hundreds of tracks: ~2.3e5 short-term energies in C4, where the
@@ -863,21 +945,19 @@ __global__ void lgd_album_final_kernel(const double *__restrict__ part1_all,
 }
 
 // ------------------------------------------------------- launch wrappers ---
+// skip_big: lists longer than LGD_LRA_BIG are left to the lgd_lra_big_* launches (lgd_launch_lra_big)
 extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_slices,
                                                 const LgdTrackMeta *meta, int n_tracks,
                                                 const double *E, double *Z, double *st,
                                                 const float *peaks, double *p1, double *p2,
-                                                double *pmax_s, double *res, double abs_gate,
-                                                double rel_factor, int do_tp, hipStream_t s) {
-  if (n_tracks <= 0) return hipSuccess;
-  if (n_slices > 0) {
-    hipLaunchKernelGGL(lgd_gate_pass1, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, E, Z, st,
-                       p1, pmax_s, abs_gate);
-    hipLaunchKernelGGL(lgd_gate_pass2, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, Z, p1, p2,
-                       (const double *)nullptr, 0, 0LL, abs_gate, rel_factor);
-  }
-  hipLaunchKernelGGL(lgd_track_final, dim3(n_tracks), dim3(LGD_EPI_NT), 0, s, meta, p1, p2, pmax_s, peaks,
-                     res, rel_factor, do_tp);
+                                                double *pmax_s, double *res, unsigned *done_count,
+                                                double abs_gate, double rel_factor, double minus20, int do_tp,
+                                                int skip_big, hipStream_t s) {
+  if (n_tracks <= 0 || n_slices <= 0) return hipSuccess;  // (every track has at least one slice)
+  hipLaunchKernelGGL(lgd_gate_pass1, dim3(n_slices), dim3(LGD_EPI_NT), 0, s, slices, meta, E, Z, st, p1, pmax_s,
+                     abs_gate);
+  hipLaunchKernelGGL(lgd_track_finish_kernel, dim3(n_slices + n_tracks), dim3(LGD_EPI_NT), 0, s, slices, n_slices,
+                     meta, Z, st, peaks, p1, p2, pmax_s, res, done_count, abs_gate, rel_factor, minus20, do_tp, skip_big);
   return hipGetLastError();
 }
 
@@ -885,13 +965,14 @@ extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_sl
 // kernels and the single-workgroup kernel skips them.  scratch: hist [n_big][8][65536] u32, part
 // [n_big][64][4] f64, picks [n_big], cand [sum 2 n_i] f64 with cand_off [n_big].
 extern "C" size_t lgd_lra_pick_bytes(void) { return sizeof(LgdLraPick); }
+// small_too 0: only the long lists (the short ones of a plan's tracks are done by lgd_track_finish_kernel)
 extern "C" hipError_t lgd_launch_lra(const void *ranges, int n_ranges, const double *st_base,
                                      double minus20, const int *big_idx, int n_big, unsigned *hist,
                                      double *part, void *picks, double *cand, const long long *cand_off,
-                                     hipStream_t s) {
+                                     int small_too, hipStream_t s) {
   if (n_ranges <= 0) return hipSuccess;
   const LgdRange *rg = (const LgdRange *)ranges;
-  if (n_big < n_ranges)
+  if (small_too && n_big < n_ranges)
     hipLaunchKernelGGL(lgd_lra_kernel, dim3(n_ranges), dim3(LGD_LRA_NT), 0, s, rg, st_base, minus20,
                        n_big > 0 ? 1 : 0);
   if (n_big > 0) {

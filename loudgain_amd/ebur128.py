@@ -22,7 +22,7 @@ EBUR128_SYMBOLS = [
     "ebur128_get_version", "ebur128_init", "ebur128_destroy", "ebur128_add_frames_short",
     "ebur128_add_frames_float", "ebur128_loudness_global", "ebur128_loudness_global_multiple",
     "ebur128_loudness_range", "ebur128_loudness_range_multiple", "ebur128_sample_peak",
-    "ebur128_true_peak", "loudscan_ebur128_set_device",
+    "ebur128_true_peak", "loudscan_ebur128_set_device", "loudscan_ebur128_plan_count",
 ]
 
 
@@ -54,8 +54,14 @@ def lib():
         for n in ("ebur128_sample_peak", "ebur128_true_peak"):
             getattr(L, n).argtypes = [P, C.c_uint, C.POINTER(C.c_double)]
         L.loudscan_ebur128_set_device.argtypes = [C.c_int]
+        L.loudscan_ebur128_plan_count.restype = C.c_ulonglong
         _bound = True
     return L
+
+
+def plan_count():
+    """scans (plans) the shim has run so far in this process"""
+    return int(lib().loudscan_ebur128_plan_count())
 
 
 def get_version():

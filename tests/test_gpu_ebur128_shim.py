@@ -82,3 +82,41 @@ def test_init_limits():
     for ch, rate in [(0, 48000), (65, 48000), (2, 8), (2, 3000000)]:
         with pytest.raises(ebur128.Ebur128Error):
             ebur128.State(ch, rate)
+
+
+def test_loudgain_main_sequence_is_one_plan(oracle):
+    """/root/reference/src/loudgain.c:299-340 through scan.c: every file scanned (init + add_frames per decoded
+    frame), THEN per file scan_get_track_result (loudness_global, loudness_range, true_peak per channel:
+    scan.c:294-306) and scan_set_album_result (both _multiple calls over all states: scan.c:383-391) and finally
+    scan_get_album_peak (true_peak of every channel of every state: scan.c:359-378).  One batched scan serves it."""
+    from loudgain_amd import ebur128
+    specs = [(48000, 2, 8.0, 11, 1.0), (48000, 2, 6.5, 12, 0.3), (44100, 1, 7.0, 13, 0.8), (48000, 6, 5.0, 14, 1.0),
+             (96000, 2, 4.2, 15, 0.6)]
+    sts, refs = [], []
+    for rate, ch, secs, seed, g in specs:
+        pcm = _s16(int(rate * secs), ch, rate, seed, g)
+        st = ebur128.State(ch, rate)
+        for a in range(0, pcm.shape[0], 4096):
+            st.add_frames(pcm[a:a + 4096])
+        sts.append(st)
+        refs.append(_oracle_state(oracle, pcm, rate))
+    before = ebur128.plan_count()
+    for st, ref in zip(sts, refs):
+        assert abs(st.loudness_global() - ref.loudness()) <= 1e-6
+        assert abs(st.loudness_range() - ref.lra()) <= 1e-6
+        for c in range(st.channels):
+            assert abs(st.true_peak(c) - ref.true_peak(c)) <= 1e-4
+        assert abs(ebur128.loudness_global_multiple(sts) - oracle.album_loudness(refs)) <= 1e-6
+        assert abs(ebur128.loudness_range_multiple(sts) - oracle.album_lra(refs)) <= 1e-6
+    peak = max(st.true_peak(c) for st in sts for c in range(st.channels))
+    assert abs(peak - max(r.peak() for r in refs)) <= 1e-4
+    assert ebur128.plan_count() - before == 1
+    # frames arriving after the queries: the next query scans again (once), results follow
+    extra = _s16(48000, 2, 48000, 99)
+    sts[0].add_frames(extra)
+    refs[0].add(extra.astype(np.float32) / 32768.0)
+    assert abs(sts[0].loudness_global() - refs[0].loudness()) <= 1e-6
+    assert abs(ebur128.loudness_global_multiple(sts) - oracle.album_loudness(refs)) <= 1e-6
+    assert ebur128.plan_count() - before == 2
+    for st in sts:
+        st.close()
