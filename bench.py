@@ -556,7 +556,7 @@ def main():
                   "two streams: see sustained_frac)" % launches if overlapped else "serial launches, as the timed region")
         line = {
             "metric": METRIC, "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
-            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 6),
             "higher_is_better": True, "scaling": "strong" if workload in ("c4", "c5") else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
@@ -594,7 +594,7 @@ def main():
         dt3, res3 = run.run(job3, c3steps, warmup, False)
         c3 = {"workload": describe(args, "c3", 1, False),
               "value": round(my_samples * c3steps / dt3 / 1e6, 1), "unit": "Msamples/s",
-              "steps": c3steps, "ms_per_step": round(dt3 / c3steps * 1e3, 4),
+              "steps": c3steps, "ms_per_step": round(dt3 / c3steps * 1e3, 6),
               "roofline": dict(roofline_block(algo_bytes, ks3, dt3 / c3steps, traffic_from_profiles("c3"),
                                               "64 serial launches; pipelined timed region",
                                               "lgd_scan_kernel + lgd_peak_reduce_kernel + lgd_tp_kernel"),
@@ -639,7 +639,7 @@ def main():
         al4 = res4[1] if isinstance(res4[1], dict) else res4[1][0]
         line["c4"] = {"workload": describe(args, "c4", 1, False), "n_gpus": 1, "scaling": "strong",
                       "value": round(s4 * steps4 / dt4 / 1e6, 1), "unit": "Msamples/s", "steps": steps4,
-                      "ms_per_step": round(dt4 / steps4 * 1e3, 4), "samples_per_step": s4,
+                      "ms_per_step": round(dt4 / steps4 * 1e3, 6), "samples_per_step": s4,
                       "segments": sc.plan_info()["segments"],
                       "roofline": roofline_block(s4 * 4, ks4, dt4 / steps4, None, "8 serial launches; pipelined timed region",
                                                  "lgd_scan_kernel + lgd_peak_reduce_kernel + lgd_tp_kernel"),

@@ -239,14 +239,17 @@ int scan_states(const std::vector<ebur128_state *> &sts) {
   return EBUR128_SUCCESS;
 }
 
-// a single-state query: served from the cache, else by one plan over EVERY live state that holds frames (the
-// caller is most likely about to ask for the others and for their album: loudgain.c:334-340)
+// a single-state query: served from the cache, else by one plan over EVERY live state that holds frames not yet
+// scanned (the caller is most likely about to ask for the others and for their album: loudgain.c:334-340;
+// states whose results are up to date are left alone)
 int scan_one(ebur128_state *st) {
   const bool want_tp = (st->mode & EBUR128_MODE_TRUE_PEAK) == EBUR128_MODE_TRUE_PEAK;
   if (fresh(st, want_tp)) return EBUR128_SUCCESS;
   std::vector<ebur128_state *> sts;
-  for (ebur128_state *s : g_live)
-    if (s == st || (s->d->frames && s->d->device == st->d->device)) sts.push_back(s);
+  for (ebur128_state *s : g_live) {
+    const bool s_tp = (s->mode & EBUR128_MODE_TRUE_PEAK) == EBUR128_MODE_TRUE_PEAK;
+    if (s == st || (s->d->frames && s->d->device == st->d->device && !fresh(s, s_tp))) sts.push_back(s);
+  }
   return scan_states(sts);
 }
 

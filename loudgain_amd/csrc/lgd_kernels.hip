@@ -263,7 +263,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // wave waits for it.  Measured run to run, the true-peak variant of the stereo kernel was 0 to
   // 6 % slower than the plain one with one store per 8 tiles; 5.1 as triples with true peak 0.388 ->
   // 0.367 ms, 7.1 0.399 -> 0.393 ms for 345.6 M samples.)
-  constexpr int LGD_ROW_PARK = (TP != 0 && ((G >= 1 && G <= 2) || G == 8)) ? 5 : ((TP != 0 && G == 3 && STR) ? 2 : 0);
+  constexpr int LGD_ROW_PARK = (TP != 0 && ((G >= 1 && G <= 2) || (G == 3 && STR) || G == 8)) ? 5 : 0;
   u32x4 parked[LGD_ROW_PARK + 1];
 #pragma unroll
   for (int i = 0; i < LGD_ROW_PARK; ++i) parked[i] = (u32x4)(0u);
@@ -873,10 +873,11 @@ struct TpCfg {
 // memory latency whatever LGD_TP_RPW is -- and the kernel's fixed cost, the sweep over rows with nothing to do
 // (72 000 of them in C3: 11.7 us at one row per wave), falls with the number of waves.  Consecutive rows go to
 // different waves: a loud passage (consecutive tiles) is spread over a segment's waves.
-#ifndef LGD_TP_RPW
-#define LGD_TP_RPW 1
-#endif
-template <int U, int TP, int NS>
+// (RPW = 4 only for launches of a million rows and more -- C4's album: 5.4 M rows, 0.95 -> 0.62 ms.  With few
+// rows the four rows of a wave make its life four times as long and the kernel's last, partly filled round of
+// waves with it: C3's 72 000 dense rows 0.306 -> 0.329 ms; its sweep over empty rows is a latency floor, 8 us,
+// that fewer waves do not lower.)
+template <int U, int TP, int NS, int LGD_TP_RPW>
 __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const LgdSeg *__restrict__ segs) {
   using K = TpCfg<U, TP, NS>;
   constexpr int HX = K::HX, LP = K::LP;
@@ -936,9 +937,8 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const L
     rec[i] = ((const u32x4 LGD_GLOBAL *)sg.tp_rows)[((size_t)g_ * nch + ch) * LGD_WAVE + lane];
   }
   // lane i keeps what row i needs later: the loop over the wave's rows below is not unrolled
-  unsigned v_mlo = 0u, v_mhi = 0u;
-  int v_k = -1, v_chan = 0;
-  float v_pthr = -1.f;
+  // (what row i needs later waits in LDS, not in lanes of VGPRs: five registers less around the loop below)
+  __shared__ unsigned rowinfo[LGD_TP_WAVES][LGD_TP_RPW][5];
   bool any_row = false;
 #pragma unroll
   for (int i = 0; i < LGD_TP_RPW; ++i) {
@@ -951,12 +951,16 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const L
       m = __ballot(bnd > pthr);
     }
     any_row = any_row || m != 0ull;
-    if (lane == i) {
-      v_mlo = (unsigned)m; v_mhi = (unsigned)(m >> 32);
-      v_k = rk[i]; v_chan = rchan[i]; v_pthr = pthr;
+    if (lane == 0) {
+      unsigned *ri_ = rowinfo[wave][i];
+      ri_[0] = (unsigned)m; ri_[1] = (unsigned)(m >> 32);
+      ri_[2] = (unsigned)rk[i]; ri_[3] = (unsigned)rchan[i]; ri_[4] = __float_as_uint(pthr);
     }
   }
   if (!any_row) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // rowinfo: written by lane 0, read by the wave below
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   float tpa[12 + 1], tpb[6 + 1];
   f32x2 tpsd[6 + 1];  // 4x: halved (sum, difference) coefficients of the mirrored phase pair
 #pragma unroll
@@ -971,12 +975,13 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const L
   float *const buf = stage[wave];
 #pragma nounroll
   for (int ri = 0; ri < LGD_TP_RPW; ++ri) {
-  const unsigned long long mask = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v_mlo, ri) |
-                                  ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v_mhi, ri) << 32);
+  const unsigned *ri_ = rowinfo[wave][ri];
+  const unsigned long long mask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ri_[0]) |
+                                  ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ri_[1]) << 32);
   if (mask == 0ull) continue;
-  const int k = __builtin_amdgcn_readlane(v_k, ri);
-  const int chan = __builtin_amdgcn_readlane(v_chan, ri);
-  const float pthr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v_pthr), ri));
+  const int k = __builtin_amdgcn_readfirstlane((int)ri_[2]);
+  const int chan = __builtin_amdgcn_readfirstlane((int)ri_[3]);
+  const float pthr = __int_as_float(__builtin_amdgcn_readfirstlane((int)ri_[4]));
   const long long tb = sg.f0 + (long long)k * tile_f;
   const gflt_ptr pcm = (gflt_ptr)sg.pcm + chan;
   const int n_chunks = __popcll(mask);
@@ -1037,6 +1042,8 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const L
       return s;
     };
     float pre[K::NPRE_D];
+#pragma unroll
+    for (int r = 0; r < K::NPRE_D; ++r) pre[r] = 0.f;  // (defined on every path: no value carried around the loop over the wave's rows)
     // element e = r * 64 + lane of slab s is frame tb + s * 64 LP - HX + e (the rounds past the slab's
     // 64 LP + HX elements are staged along, never read)
     auto fetch_slab = [&](const int s) {
@@ -1318,12 +1325,14 @@ extern "C" int lgd_tp_instance(int chunk, int *u_out, int *ns_out) {
 extern "C" hipError_t lgd_launch_tp(int u, int tp, int ns, const LgdSeg *segs, int n_seg, int rows_max,
                                     hipStream_t s) {
   if (n_seg <= 0 || rows_max <= 0 || !tp) return hipSuccess;
-  const dim3 grid((unsigned)n_seg, (unsigned)((rows_max + LGD_TP_WAVES * LGD_TP_RPW - 1) / (LGD_TP_WAVES * LGD_TP_RPW)));
+  const int rpw = (long long)n_seg * rows_max >= 1000000ll ? 4 : 1;
+  const dim3 grid((unsigned)n_seg, (unsigned)((rows_max + LGD_TP_WAVES * rpw - 1) / (LGD_TP_WAVES * rpw)));
   const dim3 block(LGD_WAVE * LGD_TP_WAVES);
   if ((long long)rows_max >= (1ll << 26)) return hipErrorInvalidValue;  // (row / nch by umulhi: exact below 2^26)
 #define LGD_TP_CASE(u_, tp_, ns_)                                                         \
   if (u == u_ && tp == tp_ && ns == ns_) {                                                \
-    hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_>), grid, block, 0, s, segs);           \
+    if (rpw == 4) hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, 4>), grid, block, 0, s, segs); \
+    else hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, 1>), grid, block, 0, s, segs);   \
     return hipGetLastError();                                                             \
   }
   LGD_TP_CASE(5, 4, 3) LGD_TP_CASE(7, 4, 3) LGD_TP_CASE(5, 2, 3) LGD_TP_CASE(7, 2, 3)
