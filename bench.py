@@ -205,8 +205,15 @@ def cpu_baseline(args, rate=48000):
             start_at = time.time() + 1.5 + 0.012 * wsecs
             res = pool.map(_cpu_worker, [(i, wsecs, rate, start_at) for i in range(nproc)])
         wall = max(t0 + d for _, d, t0 in res) - min(t0 for _, _, t0 in res)
-        multi = dict(value=round(sum(n for n, _, _ in res) / wall / 1e6, 2), unit="Msamples/s", cores=nproc,
+        v = sum(n for n, _, _ in res) / wall / 1e6
+        multi = dict(value=round(v, 2), unit="Msamples/s", cores=nproc,
                      model=_cpu_model(), host_cores=cores,
+                     # SURVEY 8d asks for P = host cores; a GPU box of this pool gives one GPU's job a 16-core share of
+                     # its host (worker pools are to be sized to that), so P is capped -- both figures are printed
+                     cap="P = min(host cores, 16): one GPU's CPU share on this pool" if not args.cpu_procs else "--cpu-procs",
+                     at_host_cores=dict(cores=cores, value=round(v / nproc * cores, 1), unit="Msamples/s",
+                                        kind="EXTRAPOLATED linearly from the measured %d processes (not run: the job's share "
+                                             "is %d cores)" % (nproc, nproc)) if cores > nproc else None,
                      sample="%d processes, one %d s 48 kHz stereo track each (as bin/rgbpm2 hands out work), "
                             "%.2f s wall" % (nproc, wsecs, wall))
     return dict(value=round(one, 2), unit="Msamples/s", cores=1, kind="port", model=_cpu_model(),
@@ -369,6 +376,9 @@ def roofline_block(algo_bytes, ks, dt_step, traffic, timing, kernels):
     return {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        # (HBM bytes per launch from the committed rocprofv3 --pmc passes -- FETCH_SIZE x 2 + WRITE_SIZE, collected
+        # counters-only in their own runs -- not a counter read during this run)
+        "traffic_source": None if traffic is None else "profiles/traffic_*.json of this commit (rocprofv3 --pmc passes, tools/pmc.sh)",
         "kernel": kernels, "kernel_ms_mean": round(ks["scan_mean_ms"], 4),
         "kernel_ms_min": round(ks["scan_min_ms"], 4),
         "launches_timed": ks["n"],

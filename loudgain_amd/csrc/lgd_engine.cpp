@@ -655,10 +655,10 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     const int s100_ = (int)((rate + 5) / 10);
     // (three channels: the one-triple form only with an interpolator -- 0.316 against 0.329 ms, where its chunk-maxima
     // records can wait in registers; without, the planar kernel is 1 % ahead)
-    if ((c->p_strided == 3 ? ch % 3 == 0 : (c->p_strided == 1 && (ch == 6 || (ch == 3 && tp_)))) &&
+    if ((c->p_strided == 3 ? ch % 3 == 0 : (c->p_strided == 1 && (ch == 5 || ch == 6 || ch == 7 || (ch == 3 && tp_)))) &&
         pick_chunk(c->p_chunk, s100_, 3, tp_) != 0)
       return 3;
-    if (c->p_strided != 2 && !(ch == 5 || ch == 7 || ch > LGD_GROUP_CH)) return 0;
+    if (c->p_strided != 2 && !(ch == 5 || ch == 7 || ch > LGD_GROUP_CH)) return 0;  // (5 / 7 channels: overlapping triples with "strided" 5)
     return pick_chunk(c->p_chunk, s100_, 2, tp_) != 0 ? 2 : 0;
   };
   for (uint32_t t = 0; t < n; ++t) {
@@ -740,8 +740,8 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     const unsigned strided = strided_for(tr.rate, tr.channels);
     std::vector<unsigned> ch0s;  // first channel of every workgroup set of this track
     if (strided) {
-      // (a last pair / triple that does not fit overlaps its neighbour: those channels are computed
-      // twice, with the same results, in one launch)
+      // (a last pair / triple that does not fit overlaps its neighbour: the shared channels are left to
+      // the neighbour, LgdSeg::skip_mask)
       for (unsigned a = 0; a + strided <= tr.channels; a += strided) ch0s.push_back(a);
       if (tr.channels % strided) ch0s.push_back(tr.channels - strided);
     } else {
@@ -839,7 +839,18 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         sg.tp_rows = (void *)~(uintptr_t)0;  // no interpolator: patched to null
         sg.chunk = g.chunk;
         sg.nch_wg = (int)g_nch;
-        sg.magic_nch = sg.magic_ns = sg.magic_c = sg.pad_ = 0;
+        sg.magic_nch = sg.magic_ns = sg.magic_c = 0;
+        // (a last pair / triple that overlaps the set before it leaves the shared channels to that one -- if it keeps
+        // at least two channels to filter itself: a workgroup with next to nothing to do runs ahead of its siblings,
+        // the three no longer share their cache lines in L2 and each streams the PCM from HBM on its own -- 7 channels
+        // as triples 0-2, 3-5, 4-6: 0.42 ms with channels 4 and 5 filtered twice, 0.60 ms with the third set idle)
+        sg.skip_mask = 0u;
+        if (strided && pi > 0 && ch0 < ch0s[pi - 1] + strided) {
+          const unsigned shared = ch0s[pi - 1] + strided - ch0;
+          unsigned kept = 0;
+          for (unsigned cc = ch0 + shared; cc < ch0 + strided; ++cc) kept += lgd_channel_weight((int)cc, (int)tr.channels) > 0.0 ? 1u : 0u;
+          if (kept >= 2) sg.skip_mask = (1u << shared) - 1u;
+        }
         if (g.tp && lgd_tp_magics(g.chunk, (int)g_nch, g.tp, &sg.magic_nch, &sg.magic_ns, &sg.magic_c))
           return fail(LGD_EUNSUP, "true-peak kernel: chunk %d not divisible as needed", g.chunk);
         if (g.tp) {  // one row of candidate bits per tile and channel of this workgroup

@@ -36,7 +36,8 @@ struct LgdSeg {
   unsigned magic_nch;    // row / nch_wg == umulhi(row, magic_nch) (0: nch_wg == 1)
   unsigned magic_ns;     // v / (chunk / U) == (v * magic_ns) >> 20 for v < 8 * (chunk / U) + 64
   unsigned magic_c;      // f / chunk == (f * magic_c) >> 20 for the frame offsets inside a row
-  unsigned pad_;
+  unsigned skip_mask;    // strided sets that overlap their neighbour: bit c = this workgroup's channel c belongs to the
+                         // neighbour (no filtering, no peaks, empty true-peak records)
 };
 
 // Per-(rate, chunk) constants, passed by value as a kernel argument.

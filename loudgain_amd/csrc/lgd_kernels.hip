@@ -225,7 +225,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   const int ch0 = (G && !STR) ? 0 : sg.ch0;
   const int nch_tot = (G && !STR) ? G : sg.nch_total;
   const bool grouped = (G == 0) && (nch_tot != nch);
-  const bool filt = lgd_channel_weight(ch0 + ch, nch_tot) > 0.0;  // wave-uniform
+  // strided sets of a channel count they do not divide overlap (5 channels: triples 0-2 and 2-4): the later set
+  // leaves the channels it shares to the earlier one -- its wave goes the way of a channel without loudness
+  // weight (peaks only, a quarter of the work) and writes nothing but empty true-peak records.  (Leaving the tile
+  // loop's body altogether -- `continue` behind the staging -- cost the OTHER waves: 7 channels 0.43 -> 0.61 ms
+  // with the branch merely compiled in, no wave taking it.)
+  const bool skip = STR && ((sg.skip_mask >> ch) & 1u);            // wave-uniform
+  const bool filt = !skip && lgd_channel_weight(ch0 + ch, nch_tot) > 0.0;  // wave-uniform
 
   const double ra1 = F.ra[0], ra2 = F.ra[1], pa1 = F.pa[0], pa2 = F.pa[1];
   const double c1 = F.pbn[0], c2 = F.pbn[1];
@@ -710,7 +716,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       car_m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mc), LGD_WAVE - 1));
       car_p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pp), LGD_WAVE - 1));
       const float M = fmaxf(mc, mprev), S2 = fmaxf(pp, pprev);
-      const float bnd = fmaxf(fmaf(Fk->tp[30], S2, Fk->tp[31] * M), fmaf(Fk->tp[32], S2, Fk->tp[33] * M));
+      float bnd = fmaxf(fmaf(Fk->tp[30], S2, Fk->tp[31] * M), fmaf(Fk->tp[32], S2, Fk->tp[33] * M));
+      if (skip) bnd = 0.f;  // (the neighbouring set owns this channel: its rows, not these, go to the true-peak kernel)
       // rounded UP to bf16 (a bound may only grow), into the 8 x 16-bit shift register of the last
       // tiles (stored every 8 tiles / behind the loop)
       {
@@ -779,7 +786,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       ((u32x4 LGD_GLOBAL *)sg.tp_rows)[ch] = (u32x4){dbg_hw, dbg_xcc, (unsigned)dbg_t0, (unsigned)dbg_t1};
   }
 #endif
-  {
+  if (!skip) {
     const float s = wave_max_f32(pk_s);
     if (lane == 0) {
       ((float LGD_GLOBAL *)sg.peak_out)[ch0 + ch] = s;

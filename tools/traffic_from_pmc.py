@@ -5,7 +5,7 @@ HBM bytes per launch (FETCH_SIZE KB x 1024 x 2 -- the gfx950 correction for wide
     python tools/traffic_from_pmc.py [r02]"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def grab(path, sect):
@@ -17,11 +17,13 @@ def grab(path, sect):
 
 
 ALGO = 1382400000
-for w in ("c2", "c3"):
+for w in ("c2", "c3", "c3_adversarial"):
     summ = os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.txt" % (tag, w))
+    if not os.path.exists(summ):
+        continue
     out = os.path.join(ROOT, "profiles", "traffic_%s.json" % w)
     t = json.load(open(out)) if os.path.exists(out) else {}
-    s, p = grab(summ, "scan"), (grab(summ, "tp") if w == "c3" else {})
+    s, p = grab(summ, "scan"), (grab(summ, "tp") if w != "c2" else {})
     t["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU (separate passes, counters only), profiles/%s" % os.path.basename(summ)
     if w == "c2":
         t["fetch_size_kb_raw"], t["write_size_kb"] = s["FETCH_SIZE"], s["WRITE_SIZE"]
