@@ -105,8 +105,10 @@ const char *lgd_last_error(void);
 
 /* tuning knobs: "chunk" (frames per lane, 0 = auto), "seg_subblocks" (100 ms
  * sub-blocks per wave segment, 0 = auto), "warm_subblocks" (K-filter warm-up
- * before a segment, default 2 = 200 ms: measured 2e-16 relative to any longer warm-up), "waves_per_cu" (auto segmentation target), "timing" (1 = bracket the scan kernel
- * with hipEvents for lgd_kernel_ms_stats, default; 0 = no event packets), "overlap"
+ * before a segment, default 2 = 200 ms: measured 2e-16 relative to any longer warm-up), "waves_per_cu" (auto segmentation target), "timing" (1 = bracket the kernels that
+ * read PCM and the whole scan with hipEvents for lgd_kernel_ms_stats, default; 2 = one more marker between the scan
+ * kernels and the true-peak kernels, for lgd_scan_only_ms_stats -- it costs ~5 us of queue time inside the bracket;
+ * 0 = no event packets), "overlap"
  * (0 = every scan runs on the caller's stream, in stream order like any kernel, default;
  * 1 = consecutive lgd_execute calls alternate between the caller's stream and an internal
  * one so that independent scans pipeline -- then a scan may still be READING its PCM after
@@ -115,9 +117,11 @@ const char *lgd_last_error(void);
  * (short-term slots in album record 1, see the multi-GPU album below; 0 = this plan's own),
  * "tp_prune" (1 = the true-peak interpolator is evaluated only where it can exceed the track's
  * sample peak -- exact, default; 0 = everywhere: the reference mode of the pruning tests),
+ * "tp_dense_min" (rows of a tile with at least this many of their 64 chunks flagged are walked as a whole by
+ * lgd_tp_kernel instead of chunk by chunk; default 32, 65 = never),
  * "album_world" (ranks the scratch of the multi-GPU album's loudness range is sized for, default 8),
  * "strided" (3+ channel streams as one workgroup per channel pair or triple of every segment: 0 never,
- * 1 where measured faster = pairs for 5 / 7 / 17+ channels, triples for 5.1 (and for 3 channels with true peak), default; 2 pairs always;
+ * 1 where measured faster = triples for 5 / 5.1 / 7 channels (and for 3 channels with true peak), pairs for 17+ channels, default; 2 pairs always;
  * 3 triples wherever the channel count divides by three), "merge_launches" (1, default: the (rate, channels) groups of a plan that run the same kernel
  * instance -- e.g. its 48, 96 and 192 kHz stereo tracks -- are scanned by one launch, sized to fill the GPU
  * together; 0: one launch per group), "group_streams" (1 = the groups of a
