@@ -645,3 +645,58 @@ def test_non_finite_samples_stay_in_their_track(oracle):
             assert got[k] == want[k], k
         check_track(got, oracle.scan_track(pcm, rate))
     assert res[1]["n_blocks"] == 87       # 9 s: the block grid does not depend on the samples
+
+
+@pytest.mark.parametrize("rate,nch", [(48000, 2), (44100, 2), (96000, 2), (48000, 1), (48000, 6), (88200, 1)])
+def test_limited_programme_dense_true_peak_rows(scanner, oracle, rate, nch):
+    """Loud, hard-limited material: the sample peak is reached everywhere, (nearly) every chunk's bound exceeds it and
+    lgd_tp_kernel walks whole rows (dense path: 4x at 44.1 / 48 kHz with window steps of 7 / 5 frames, 2x at 88.2 / 96 kHz) --
+    per channel against the oracle's interp_process restatement (oracle/lg_oracle.c:156-179), and against the same scan with
+    the dense path switched off ("tp_dense_min" 65: chunk by chunk) bit for bit."""
+    from loudgain_amd.device import DeviceScanner
+    pcm = synth.limited_numpy(rate * 9 + 1234, nch, rate, seed=rate % 89 + nch)
+    ref = oracle.scan_track(pcm, rate)
+    sc = DeviceScanner(0)
+    out = []
+    for dm in (32, 65):
+        sc.set_param("tp_dense_min", dm)
+        (got,), _ = sc.scan([to_dev(pcm)], rate)
+        sp, tp = sc.channel_peaks(0, nch)
+        out.append((got, list(sp), list(tp)))
+    sc.close()
+    (got, sp, tp), (got2, sp2, tp2) = out
+    check_track(got, ref, rate=rate)
+    assert sp == ref["sample_peak"]
+    for c in range(nch):
+        assert abs(tp[c] - ref["true_peak"][c]) <= 1e-4, (c, tp[c], ref["true_peak"][c])
+    assert tp == tp2 and sp == sp2 and got["peak"] == got2["peak"]
+    assert max(tp) > max(sp) * 1.05        # the limiter's flat tops overshoot between the samples: the interpolator matters here
+
+
+@pytest.mark.parametrize("nch", [5, 7])
+def test_overlapping_channel_triples(oracle, nch):
+    """5 and 7 channels go out as overlapping channel triples (0-2 | 2-4; 0-2 | 3-5 | 4-6), the later set leaving shared
+    channels to its neighbour where it keeps two to filter (LgdSeg::skip_mask): per channel against the oracle, and equal to
+    the pairs form ("strided" 2) and the run-time-channel kernel ("strided" 0) bit for bit in everything but summation-free
+    quantities' order -- energies are per channel, so all three must agree exactly."""
+    from loudgain_amd.device import DeviceScanner
+    rate = 48000
+    pcm = synth.track_numpy(rate * 11 + 321, nch, rate, seed=70 + nch, step_s=2.3)
+    pcm *= (1.0 - 0.07 * np.arange(nch, dtype=np.float32))[None, :]
+    pcm = synth.snap_s16_numpy(pcm)
+    ref = oracle.scan_track(pcm, rate)
+    res = {}
+    for st in (1, 2, 0):
+        sc = DeviceScanner(0)
+        sc.set_param("strided", st)
+        (got,), _ = sc.scan([to_dev(pcm)], rate)
+        sp, tp = sc.channel_peaks(0, nch)
+        res[st] = (got, list(sp), list(tp), sc.plan_info()["chunk"])
+        sc.close()
+    assert res[1][3] == 50 and res[2][3] == 75 and res[0][3] == 25   # triples, pairs, run-time-channel kernel
+    for st, (got, sp, tp, _) in res.items():
+        check_track(got, ref, rate=rate)
+        assert sp == ref["sample_peak"], (st, sp, ref["sample_peak"])
+        for c in range(nch):
+            assert abs(tp[c] - ref["true_peak"][c]) <= 1e-4, (st, c)
+    assert res[1][1] == res[2][1] == res[0][1]
