@@ -89,6 +89,7 @@ def test_one_rank_rccl_rehearsal():
                "--no-cpu-baseline", "--force-dist")
     c = d["collective"]
     assert c["backend"] == "nccl" and c["world_size"] == 1 and c["bytes_gathered_per_rank_per_step"] > 0
+    assert c["ranks_folded"] == {"stage2_heads": 1, "with_content": 1, "stage3_records": 1}
     assert d["result"]["album"]["n_abs"] > 0
 
 
@@ -105,5 +106,7 @@ def test_two_ranks_rehearsal_on_one_gpu():
     assert d["config"]["samples_per_step_all_ranks"] == sum(bench.c4_track_frames(t, scale=0.05) * 2 for t in range(11))
     c = d["collective"]
     assert c["world_size"] == 2 and c["backend"] == "gloo" and c["bytes_gathered_per_rank_per_step"] > 0
+    # counted by the album kernels on the device and read back with the album result: both ranks' records were folded
+    assert c["ranks_folded"] == {"stage2_heads": 2, "with_content": 2, "stage3_records": 2}
     assert abs(d["value"] - d["config"]["samples_per_step_all_ranks"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
     assert d["result"]["album"]["n_abs"] > d["result"]["n_abs"] > 0
