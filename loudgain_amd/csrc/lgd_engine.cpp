@@ -647,7 +647,9 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   // 44 / 29 / 19 % against 54 / 56 / 45 / 41 / 42 % on the planar kernels.
   // 5.1 (six channels) goes out as two channel TRIPLES: three-wave workgroups spread evenly over a
   // CU's SIMDs (four per CU at C = 50), the planar kernel's six-wave workgroups do not (two per CU
-  // land 4 / 4 / 2 / 2 waves on a quarter of the CUs, tools/hwid_probe.py).
+  // land 4 / 4 / 2 / 2 waves on a quarter of the CUs, tools/hwid_probe.py).  5 and 7 channels as
+  // OVERLAPPING triples (0-2 | 2-4; 0-2 | 3-5 | 4-6), one kernel instance and one launch per track set:
+  // 48 % / 45 % of the HBM peak against 40 % / 35 % as pairs (round 3, tools/odd_probe.py).
   // Returns the channels per workgroup: 0 = not strided, 2 = pairs, 3 = triples.
   auto strided_for = [&](unsigned rate, unsigned ch) -> unsigned {
     if (!c->p_strided || ch < 3) return 0;
@@ -658,7 +660,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if ((c->p_strided == 3 ? ch % 3 == 0 : (c->p_strided == 1 && (ch == 5 || ch == 6 || ch == 7 || (ch == 3 && tp_)))) &&
         pick_chunk(c->p_chunk, s100_, 3, tp_) != 0)
       return 3;
-    if (c->p_strided != 2 && !(ch == 5 || ch == 7 || ch > LGD_GROUP_CH)) return 0;  // (5 / 7 channels: overlapping triples with "strided" 5)
+    if (c->p_strided != 2 && !(ch == 5 || ch == 7 || ch > LGD_GROUP_CH)) return 0;  // (5 / 7 channels: pairs only if no triple chunk divides the rate's sub-block)
     return pick_chunk(c->p_chunk, s100_, 2, tp_) != 0 ? 2 : 0;
   };
   for (uint32_t t = 0; t < n; ++t) {

@@ -862,7 +862,7 @@ extern "C" hipError_t lgd_launch_peak_reduce(const LgdTrackMeta *meta, int n_tra
 // folded into the segment's interpolated peak with an atomic max on the float bits
 // (non-negative floats order like their bits).
 #define LGD_TP_WAVES 4
-#define LGD_TP_GROUP 8     // accepted chunks evaluated together (sparse rows)
+#define LGD_TP_GROUP 8     // flagged chunks staged and evaluated together (sparse rows)
 #define LGD_TP_CHMAX 100   // frames of one staged chunk at most: C + HX
 #define LGD_TP_AHEAD 3     // sparse rows: flagged chunks whose loads are in flight ahead of the one being looked at
 // U frames per window step, TP interpolation factor, NS steps per lane of a dense slab (LP = U NS frames)
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const L
         r1 = in1 ? pcm[(in1 ? f + LGD_WAVE : 0) * nch_tot] : 0.f;
       }
     };
-    // evaluates the n accepted chunks staged in `buf` (ids in chunk_of)
+    // evaluates the n flagged chunks staged in `buf` (ids in chunk_of)
     auto run_group = [&](const int n) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
