@@ -619,6 +619,10 @@ def main():
                 c3[name] = {"material": what, "kernel_ms_mean": round(ksm["scan_mean_ms"], 4),
                             "kernel_ms_min": round(ksm["scan_min_ms"], 4), "achieved": round(ach, 1),
                             "frac": round(ach / HBM_PEAK_GBS, 4)}
+            noi = synth.track_torch(tracks[0].shape[0], 2, 48000, seed=0, step_s=1e9, device=dev, sine=False)
+            other("noise", noi, "stationary Gaussian noise at one level (sample peak ~6 sigma): isolated peaks, where the "
+                                "adjacent-pair bound prunes what L1 * max|x| cannot")
+            del noi
             lim = synth.limited_torch(tracks[0].shape[0], 2, 48000, seed=0, device=dev)
             other("limited", lim, "loud, heavily limited programme: noise + tones through a hard limiter at 0.8 FS, crest "
                                   "factor ~8 dB, the sample peak is reached everywhere: (nearly) every interpolator output "
