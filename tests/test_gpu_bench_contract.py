@@ -53,7 +53,7 @@ def test_bench_line_contract():
     assert c3["peak"] >= d["result"]["peak"]
     assert 0 < c3["adversarial"]["frac"] <= c3["roofline"]["frac"] * 1.05
     assert 0 < c3["limited"]["frac"] <= c3["roofline"]["frac"] * 1.05 and "f32 interpolator" in c3["dtype"]
-    assert c3["limited"]["frac"] <= c3["noise"]["frac"] * 1.05 <= c3["roofline"]["frac"] * 1.15
+    assert 0 < c3["limited"]["frac"] <= c3["noise"]["frac"] * 1.05   # nothing prunable vs nearly everything
     assert d["step_ms"]["min"] <= d["step_ms"]["median"]
     # the N = 1 anchor of the scaling series: config 4 (here 40 short tracks) on the same line
     c4 = d["c4"]
