@@ -31,6 +31,8 @@ def _material(kind, frames, nch, rate, seed):
     n = np.arange(frames)
     if kind == "steps":            # the benchmark's programme material
         return synth.track_numpy(frames, nch, rate, seed=seed, step_s=1.3)
+    if kind == "limited":          # hard-limited programme: the sample peak is reached everywhere (dense rows)
+        return synth.limited_numpy(frames, nch, rate, seed=seed)
     if kind == "adversarial":      # fs/4 sine sampled on its peaks: sample peak == true peak in
         x = 0.8 * np.sin(2 * np.pi * n / 4.0 + np.pi / 2)   # every window, nothing can be skipped
         return synth.snap_s16_numpy(np.repeat(x[:, None], nch, 1).astype(np.float32))
@@ -71,7 +73,14 @@ def _scan_both(scanner, pcm, rate):
         (r,), _ = scanner.scan([dev], rate)
         sp, tp = scanner.channel_peaks(0, nch)
         out.append((r, sp.copy(), tp.copy()))
+    # the unpruned scan walks every row as a whole (dense rows); once more unpruned but chunk by chunk
+    # (sparse rows only): every output is computed by the same instructions whichever way it is reached
+    scanner.set_param("tp_dense_min", 65)
+    (r3,), _ = scanner.scan([dev], rate)
+    sp3, tp3 = scanner.channel_peaks(0, nch)
+    scanner.set_param("tp_dense_min", 32)
     scanner.set_param("tp_prune", 1)
+    assert r3["peak"] == out[1][0]["peak"] and np.array_equal(tp3, out[1][2]) and np.array_equal(sp3, out[1][1])
     return out
 
 
@@ -83,6 +92,11 @@ CASES = [
     ("hidden", 48000, 2, 23.9), ("hidden", 96000, 2, 12.1), ("hidden", 44100, 6, 9.3),
     ("music", 48000, 2, 29.9), ("music", 48000, 8, 6.1), ("music", 32000, 3, 11.7),
     ("impulses", 48000, 2, 14.1), ("impulses", 96000, 4, 6.3),
+    # round 3: dense rows on every true-peak kernel instance -- window steps of 5 / 7 frames x the 4x / 2x interpolator,
+    # slabs that divide the row (C = 75, 45) and that reach past it (C = 50, 70, 63, 25) -- and the channel-set forms
+    ("limited", 48000, 2, 9.3), ("limited", 44100, 2, 8.1), ("limited", 22050, 2, 14.7), ("limited", 32000, 1, 9.9),
+    ("limited", 96000, 2, 5.3), ("limited", 88200, 2, 5.9), ("limited", 176400, 2, 3.1), ("limited", 44100, 6, 5.7),
+    ("limited", 48000, 5, 5.1), ("limited", 48000, 7, 4.9), ("limited", 11025, 2, 19.0), ("limited", 48000, 20, 2.9),
 ]
 
 
