@@ -1332,13 +1332,16 @@ extern "C" int lgd_tp_instance(int chunk, int *u_out, int *ns_out) {
 extern "C" hipError_t lgd_launch_tp(int u, int tp, int ns, const LgdSeg *segs, int n_seg, int rows_max,
                                     hipStream_t s) {
   if (n_seg <= 0 || rows_max <= 0 || !tp) return hipSuccess;
-  const int rpw = (long long)n_seg * rows_max >= 1000000ll ? 4 : 1;
+#ifndef LGD_TP_RPW_BIG
+#define LGD_TP_RPW_BIG 4
+#endif
+  const int rpw = (long long)n_seg * rows_max >= 1000000ll ? LGD_TP_RPW_BIG : 1;
   const dim3 grid((unsigned)n_seg, (unsigned)((rows_max + LGD_TP_WAVES * rpw - 1) / (LGD_TP_WAVES * rpw)));
   const dim3 block(LGD_WAVE * LGD_TP_WAVES);
   if ((long long)rows_max >= (1ll << 26)) return hipErrorInvalidValue;  // (row / nch by umulhi: exact below 2^26)
 #define LGD_TP_CASE(u_, tp_, ns_)                                                         \
   if (u == u_ && tp == tp_ && ns == ns_) {                                                \
-    if (rpw == 4) hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, 4>), grid, block, 0, s, segs); \
+    if (rpw != 1) hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, LGD_TP_RPW_BIG>), grid, block, 0, s, segs); \
     else hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, 1>), grid, block, 0, s, segs);   \
     return hipGetLastError();                                                             \
   }
