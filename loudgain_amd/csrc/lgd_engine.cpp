@@ -1205,9 +1205,11 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
   // channel count and constants travel with the segments.  (Sending the launches of a mixed plan out on
   // four streams at once was measured on C5: 2.563 -> 2.546 ms of kernel time, but the event packets
   // cost the pipelined step 2.40 -> 2.62 ms: not done.)
+#ifndef LGD_FUSED_TP  // (experiment build: the scan kernel has evaluated the interpolator itself, make libloudscan_hip_fused.so)
   if (c->flags & LGD_FLAG_TRUE_PEAK)
     for (const TpLaunch &T : c->tp_launches)
       HIPCHK(lgd_launch_tp(T.u, T.tp, T.ns, w.d_segs_tp + T.seg_begin, (int)T.seg_count, T.rows_max, s));
+#endif
   if (c->p_timing) HIPCHK(hipEventRecord(ev[1], s));
   // gating pass 1, pass 2, result records and loudness ranges of all tracks: one launch (the long short-term
   // lists, > LGD_LRA_BIG entries, through the multi-workgroup kernels behind it)

@@ -253,6 +253,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   int cur = 0;            // sub-block (relative to the segment) being summed
   int cur_q = 0;          // chunk index (relative to f0) where `cur` starts
   float pk_s = 0.f;
+#ifdef LGD_FUSED_TP
+  float pk_tp = 0.f;  // experiment: the 4x interpolator for EVERY frame while the tile is in LDS (make libloudscan_hip_fused.so, tools/variant_probe.sh)
+#endif
   // (true peak: this kernel only records every chunk's largest |x|; lgd_tp_kernel decides from
   // them which interpolator outputs can matter and evaluates those)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -728,6 +731,56 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         mc_rows.w = (mc_rows.w >> 16) | (code << 16);
       }
     }
+#ifdef LGD_FUSED_TP
+    if constexpr (TP != 0) {
+      // EXPERIMENT (never in the product build): what evaluating the interpolator inside the scan kernel costs when nothing
+      // can be pruned -- every lane walks its chunk once more with a register window, as lgd_tp_kernel's dense rows do.
+      // Measured (round 3, C3): the scan kernel 0.282 -> 0.547 ms on ANY material, 0.555 ms with the peak reduction --
+      // against 0.58 ms for scan + follow-up kernel where nothing can be pruned and 0.30 ms on the standard material.
+      if (Fk->tp_hx == 11) {
+        constexpr int HXF = 11, UF = 5;
+        static_assert(C % UF == 0 || true, "");
+        f32x2 csd[6];
+        float c2f[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { csd[i] = (f32x2){Fk->tp[18 + 2 * i], Fk->tp[19 + 2 * i]}; c2f[i] = Fk->tp[12 + i]; }
+        const long long fl = tb + (long long)lane * C;
+        const long long rem_ll = n_frames - fl;
+        const int rem = rem_ll >= C ? C : (rem_ll < 0 ? 0 : (int)rem_ll);
+        float wv[UF + HXF];
+#pragma unroll
+        for (int i = 0; i < HXF; ++i) wv[i] = LGD_X(i - HXF);
+        if constexpr (C % UF == 0) {
+#pragma unroll
+          for (int st = 0; st < C / UF; ++st) {
+#pragma unroll
+            for (int u_ = 0; u_ < UF; ++u_) wv[HXF + u_] = LGD_X(st * UF + u_);
+            f32x2 sd_[UF];
+            float o2_[UF];
+#pragma unroll
+            for (int u_ = 0; u_ < UF; ++u_) { sd_[u_] = (f32x2){0.f, 0.f}; o2_[u_] = 0.f; }
+#pragma unroll
+            for (int k_ = 0; k_ < 6; ++k_) {
+#pragma unroll
+              for (int u_ = 0; u_ < UF; ++u_) {
+                const float xa_ = wv[HXF + u_ - k_], xb_ = wv[u_ + k_];
+                const f32x2 ab_ = (f32x2){xa_ + xb_, xa_ - xb_};
+                sd_[u_] = __builtin_elementwise_fma(csd[k_], ab_, sd_[u_]);
+                o2_[u_] = fmaf(c2f[k_], ab_.x, o2_[u_]);
+              }
+            }
+#pragma unroll
+            for (int u_ = 0; u_ < UF; ++u_) {
+              const float m_ = fmaxf(fabsf(o2_[u_]), fabsf(sd_[u_].x) + fabsf(sd_[u_].y));
+              pk_tp = fmaxf(pk_tp, (st * UF + u_ < rem) ? m_ : 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < HXF; ++i) wv[i] = wv[i + UF];
+          }
+        }
+      }
+    }
+#endif
 #undef LGD_X
 
     // ---- 100 ms sub-block sums: deterministic per-lane accumulate + wave tree
@@ -788,10 +841,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 #endif
   if (!skip) {
     const float s = wave_max_f32(pk_s);
+#ifdef LGD_FUSED_TP
+    const float s_tp = wave_max_f32(pk_tp);
+#endif
     if (lane == 0) {
       ((float LGD_GLOBAL *)sg.peak_out)[ch0 + ch] = s;
       // the interpolated peak of the segment: lgd_tp_kernel raises it (atomic max on the bits)
+#ifdef LGD_FUSED_TP
+      ((float LGD_GLOBAL *)sg.peak_out)[nch_tot + ch0 + ch] = TP != 0 ? s_tp : 0.f;
+#else
       ((float LGD_GLOBAL *)sg.peak_out)[nch_tot + ch0 + ch] = 0.f;
+#endif
     }
   }
 #undef F
