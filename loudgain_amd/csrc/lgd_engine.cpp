@@ -649,7 +649,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   // CU's SIMDs (four per CU at C = 50), the planar kernel's six-wave workgroups do not (two per CU
   // land 4 / 4 / 2 / 2 waves on a quarter of the CUs, tools/hwid_probe.py).  5 and 7 channels as
   // OVERLAPPING triples (0-2 | 2-4; 0-2 | 3-5 | 4-6), one kernel instance and one launch per track set:
-  // 48 % / 45 % of the HBM peak against 40 % / 35 % as pairs (round 3, tools/odd_probe.py).
+  // 48 % / 40 % of the HBM peak against 40 % / 35 % as pairs (round 3, tools/odd_probe.py).
   // Returns the channels per workgroup: 0 = not strided, 2 = pairs, 3 = triples.
   auto strided_for = [&](unsigned rate, unsigned ch) -> unsigned {
     if (!c->p_strided || ch < 3) return 0;
