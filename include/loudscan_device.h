@@ -121,7 +121,8 @@ const char *lgd_last_error(void);
  * lgd_tp_kernel instead of chunk by chunk; default 32, 65 = never),
  * "album_world" (ranks the scratch of the multi-GPU album's loudness range is sized for, default 8),
  * "strided" (3+ channel streams as one workgroup per channel pair or triple of every segment: 0 never,
- * 1 where measured faster = triples for 5 / 5.1 / 7 channels (and for 3 channels with true peak), pairs for 17+ channels, default; 2 pairs always;
+ * 1 where measured faster = triples for 5 / 5.1 channels (and for 3 channels with true peak), quads for 7 / 7.1 / 9 and for 16+ channels, default; 2 pairs always;
+ * 4 quads for every layout from 5 channels up;
  * 3 triples wherever the channel count divides by three), "merge_launches" (1, default: the (rate, channels) groups of a plan that run the same kernel
  * instance -- e.g. its 48, 96 and 192 kHz stereo tracks -- are scanned by one launch, sized to fill the GPU
  * together; 0: one launch per group), "group_streams" (1 = the groups of a

@@ -650,14 +650,24 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   // land 4 / 4 / 2 / 2 waves on a quarter of the CUs, tools/hwid_probe.py).  5 and 7 channels as
   // OVERLAPPING triples (0-2 | 2-4; 0-2 | 3-5 | 4-6), one kernel instance and one launch per track set:
   // 48 % / 40 % of the HBM peak against 40 % / 35 % as pairs (round 3, tools/odd_probe.py).
-  // Returns the channels per workgroup: 0 = not strided, 2 = pairs, 3 = triples.
+  // Returns the channels per workgroup: 0 = not strided, 2 = pairs, 3 = triples, 4 = quads.
   auto strided_for = [&](unsigned rate, unsigned ch) -> unsigned {
     if (!c->p_strided || ch < 3) return 0;
     const int tp_ = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(rate) : 0;
     const int s100_ = (int)((rate + 5) / 10);
     // (three channels: the one-triple form only with an interpolator -- 0.316 against 0.329 ms, where its chunk-maxima
     // records can wait in registers; without, the planar kernel is 1 % ahead)
-    if ((c->p_strided == 3 ? ch % 3 == 0 : (c->p_strided == 1 && (ch == 5 || ch == 6 || ch == 7 || (ch == 3 && tp_)))) &&
+    // channel QUADS (four-wave workgroups, one 16-byte load per lane and frame): 7 / 8 / 9 channels (0-3 | 3-6; 0-3 | 4-7;
+    // 0-3 | 4-7 | 5-8) and everything from 16 channels up.  Measured (round 3, tools/odd_probe.py, % of the HBM peak without /
+    // with true peak): 7 ch 52 / 45 against 40 / 37 as triples, 7.1 58 / 50 against 50 / 43 on the eight-plane kernel, 9 ch
+    // 46 / 41 against 35 / 26, 16 ch 34 / 30 against 30 / 23, 24 ch 25 / 23 against 12 / 10 as pairs, 64 ch 20 / 17 against
+    // 13 / 10; but 5 ch 40 % (triples 48), 5.1 50 % (triples 52), 10 - 15 ch 30 - 34 % against 41 - 52 % on the
+    // run-time-channel kernel (sets of nothing but peaks-only channels run ahead of their siblings).  "strided" 4: quads for
+    // every layout from 5 channels up.
+    if ((c->p_strided == 4 ? ch >= 5 : (c->p_strided == 1 && ((ch >= 7 && ch <= 9) || ch >= 16))) &&
+        pick_chunk(c->p_chunk, s100_, 4, tp_) != 0)
+      return 4;
+    if ((c->p_strided == 3 ? ch % 3 == 0 : ((c->p_strided == 1 || c->p_strided == 4) && (ch == 5 || ch == 6 || ch == 7 || (ch == 3 && tp_)))) &&
         pick_chunk(c->p_chunk, s100_, 3, tp_) != 0)
       return 3;
     if (c->p_strided != 2 && !(ch == 5 || ch == 7 || ch > LGD_GROUP_CH)) return 0;  // (5 / 7 channels: pairs only if no triple chunk divides the rate's sub-block)

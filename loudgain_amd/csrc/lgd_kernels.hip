@@ -207,7 +207,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // the constants of this segment's (rate, chunk): per segment, so that one launch can carry the
   // segments of several sample rates
   const cfilt_ptr F0 = (cfilt_ptr)sg.filt;
-  static_assert(!STR || G == 1 || G == 2 || G == 3, "strided variant: one to three channels per workgroup");
+  static_assert(!STR || G == 1 || G == 2 || G == 3 || G == 4, "strided variant: one to four channels per workgroup");
   const int shift = (STR || (G == 0 && sg.nch_total != (G ? G : nch_rt))) ? 0 : (int)((sg.f0 * nch) & 3);
   const long long n_frames = sg.n_frames;
   const int nvec = ((K::TILE_F + K::HALO) * nch + 4) >> 2;  // 16-B vectors per tile
@@ -272,7 +272,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // wave waits for it.  Measured run to run, the true-peak variant of the stereo kernel was 0 to
   // 6 % slower than the plain one with one store per 8 tiles; 5.1 as triples with true peak 0.388 ->
   // 0.367 ms, 7.1 0.399 -> 0.393 ms for 345.6 M samples.)
-  constexpr int LGD_ROW_PARK = (TP != 0 && ((G >= 1 && G <= 2) || (G == 3 && STR) || G == 8)) ? 5 : 0;
+  constexpr int LGD_ROW_PARK = (TP != 0 && ((G >= 1 && G <= 2) || ((G == 3 || G == 4) && STR) || G == 8)) ? 5 : 0;
   u32x4 parked[LGD_ROW_PARK + 1];
 #pragma unroll
   for (int i = 0; i < LGD_ROW_PARK; ++i) parked[i] = (u32x4)(0u);
@@ -317,7 +317,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   typedef const f32x2 LGD_GLOBAL *gvec2_ptr;
   typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
   typedef const f32x3u LGD_GLOBAL *gvec3_ptr;
-  f32x4 pfs[NVS];  // (.w unused; .z only by channel triples)
+  f32x4 pfs[NVS];  // (.z only by channel triples and quads, .w only by quads)
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef const f32x4u LGD_GLOBAL *gvec4u_ptr;
 #pragma unroll
   for (int i = 0; i < NVS; ++i) pfs[i] = (f32x4)(0.f);
   // (an aligned pair of channels is one 8-B load; odd channel counts take two dwords; a triple is
@@ -335,7 +337,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         gflt_ptr src_i_ = src_ + (long long)(nthreads * i_) * nch_tot;                  \
         asm volatile("" : "+s"(src_i_));                                                \
         if (nthreads * (i_ + 1) <= NFR || tid + nthreads * i_ < NFR) {                  \
-          if (G == 3) {                                                                 \
+          if (G == 4) {                                                                 \
+            const f32x4u t_ = *(gvec4u_ptr)(src_i_ + lo_);                              \
+            pfs[i_] = (f32x4){t_.x, t_.y, t_.z, t_.w};                                  \
+          } else if (G == 3) {                                                          \
             const f32x3u t_ = *(gvec3_ptr)(src_i_ + lo_);                               \
             pfs[i_].x = t_.x; pfs[i_].y = t_.y; pfs[i_].z = t_.z;                       \
           } else if (G == 2 && aligned2) {                                              \
@@ -383,18 +388,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     } while (0)
     if constexpr (STR) {
       // frame fr (0 = tile frame -HALO) of plane c sits at fr + PAD * floor((fr - HALO + C) / C)
-#define LGD_STORE_FRAME(fr_, a_, b_, c_)                                                \
+#define LGD_STORE_FRAME(fr_, a_, b_, c_, d_)                                            \
       do {                                                                              \
         const int at_ = (fr_) + LL::PAD * (int)((unsigned)((fr_) - K::HALO + C) / (unsigned)C); \
         lds[at_] = (a_);                                                                \
         if (G >= 2) lds[PLANE + at_] = (b_);                                            \
         if (G >= 3) lds[2 * PLANE + at_] = (c_);                                        \
+        if (G >= 4) lds[3 * PLANE + at_] = (d_);                                        \
       } while (0)
       if (pf_valid && !(dbg & 64)) {
 #pragma unroll
         for (int i = 0; i < NVS; ++i) {
           const int fr = tid + nthreads * i;
-          if (nthreads * (i + 1) <= NFR || fr < NFR) LGD_STORE_FRAME(fr, pfs[i].x, pfs[i].y, pfs[i].z);
+          if (nthreads * (i + 1) <= NFR || fr < NFR) LGD_STORE_FRAME(fr, pfs[i].x, pfs[i].y, pfs[i].z, pfs[i].w);
         }
       } else if (!(dbg & 1) && !(dbg & 64)) {  // a tile at a track edge: frames outside the track are zero
         const gflt_ptr gp = (gflt_ptr)sg.pcm + ch0;
@@ -404,7 +410,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           const float a = in ? gp[f * nch_tot] : 0.f;
           const float b = (in && G >= 2) ? gp[f * nch_tot + 1] : 0.f;
           const float c = (in && G >= 3) ? gp[f * nch_tot + 2] : 0.f;
-          LGD_STORE_FRAME(fr, a, b, c);
+          const float d = (in && G >= 4) ? gp[f * nch_tot + 3] : 0.f;
+          LGD_STORE_FRAME(fr, a, b, c, d);
         }
       }
 #undef LGD_STORE_FRAME
@@ -1331,6 +1338,13 @@ static hipError_t launch_scan_strided(int nch, int tp, const LgdSeg *segs, int n
     if constexpr (C <= 50) {  // (three planes: the chunk lengths the three-channel kernel is built for)
       if (tp) return launch_scan_t<C, 3, 4, false, true>(segs, n_seg, nch, s);
       return launch_scan_t<C, 3, 0, false, true>(segs, n_seg, nch, s);
+    }
+    return hipErrorInvalidValue;
+  }
+  if (nch == 4) {  // channel quads of a wider stream (7 channels: 0-3 | 3-6)
+    if constexpr (C <= 50) {
+      if (tp) return launch_scan_t<C, 4, 4, false, true>(segs, n_seg, nch, s);
+      return launch_scan_t<C, 4, 0, false, true>(segs, n_seg, nch, s);
     }
     return hipErrorInvalidValue;
   }

@@ -673,16 +673,17 @@ def test_limited_programme_dense_true_peak_rows(scanner, oracle, rate, nch):
     assert max(tp) > max(sp) * 1.05        # the limiter's flat tops overshoot between the samples: the interpolator matters here
 
 
-@pytest.mark.parametrize("nch", [5, 7])
-def test_overlapping_channel_triples(oracle, nch):
-    """5 and 7 channels go out as overlapping channel triples (0-2 | 2-4; 0-2 | 3-5 | 4-6), the later set leaving shared
-    channels to its neighbour where it keeps two to filter (LgdSeg::skip_mask): per channel against the oracle, and equal to
-    the pairs form ("strided" 2) and the run-time-channel kernel ("strided" 0) bit for bit in everything but summation-free
-    quantities' order -- energies are per channel, so all three must agree exactly."""
+@pytest.mark.parametrize("nch,width", [(5, 3), (7, 4), (8, 4), (9, 4), (16, 4), (21, 4)])
+def test_overlapping_channel_sets(oracle, nch, width):
+    """Layouts the planar kernels are weak on go out as channel triples (5 ch: 0-2 | 2-4) or quads (7: 0-3 | 3-6; 7.1: 0-3 | 4-7;
+    9: 0-3 | 4-7 | 5-8; 16+), sibling workgroups of one launch; a set that overlaps its neighbour leaves the shared channels to
+    it where it keeps two to filter (LgdSeg::skip_mask), else computes them again.  Per channel against the oracle, and equal to
+    the pairs form ("strided" 2) and the planar / run-time-channel kernels ("strided" 0): energies and peaks are per channel,
+    so all three must agree exactly."""
     from loudgain_amd.device import DeviceScanner
     rate = 48000
-    pcm = synth.track_numpy(rate * 11 + 321, nch, rate, seed=70 + nch, step_s=2.3)
-    pcm *= (1.0 - 0.07 * np.arange(nch, dtype=np.float32))[None, :]
+    pcm = synth.track_numpy(rate * 7 + 321, nch, rate, seed=70 + nch, step_s=1.3)
+    pcm *= (1.0 - 0.03 * np.arange(nch, dtype=np.float32))[None, :]
     pcm = synth.snap_s16_numpy(pcm)
     ref = oracle.scan_track(pcm, rate)
     res = {}
@@ -691,12 +692,14 @@ def test_overlapping_channel_triples(oracle, nch):
         sc.set_param("strided", st)
         (got,), _ = sc.scan([to_dev(pcm)], rate)
         sp, tp = sc.channel_peaks(0, nch)
-        res[st] = (got, list(sp), list(tp), sc.plan_info()["chunk"])
+        res[st] = (got, list(sp), list(tp), sc.plan_info()["chunk"], sc.subblock_energies(0))
         sc.close()
-    assert res[1][3] == 50 and res[2][3] == 75 and res[0][3] == 25   # triples, pairs, run-time-channel kernel
-    for st, (got, sp, tp, _) in res.items():
+    assert res[1][3] == 50 and res[2][3] == 75                                  # triples / quads at C = 50, pairs at C = 75
+    for st, (got, sp, tp, _, _) in res.items():
         check_track(got, ref, rate=rate)
         assert sp == ref["sample_peak"], (st, sp, ref["sample_peak"])
         for c in range(nch):
             assert abs(tp[c] - ref["true_peak"][c]) <= 1e-4, (st, c)
-    assert res[1][1] == res[2][1] == res[0][1]
+    assert res[1][1] == res[2][1] == res[0][1] and res[1][2] == res[2][2] == res[0][2]
+    np.testing.assert_allclose(res[1][4], res[0][4], rtol=energy_rtol(rate))
+    assert width in (3, 4)
