@@ -329,7 +329,7 @@ class Runner:
         sc.fetch()
         for _ in range(launches):
             sc.execute(self.stream)
-        sc.fetch()
+        self.last_results = sc.fetch()
         ks = sc.kernel_ms_stats(launches)
         sc.set_param("timing", 0)         # (the timed regions run without the instrumentation's event packets)
         return ks
@@ -633,6 +633,28 @@ def main():
                                       "window, no interpolator output can be pruned")
             del adv
         line["c3"] = c3
+        if args.material == "steps" and args.minutes >= 1:
+            # the same samples as the interleaved S16 the reference feeds libebur128 (scan.c:442-448), resident in HBM and
+            # read as they are (LGD_PCM_S16): 2 B per sample of HBM traffic; the algorithmic 4 B per sample of SURVEY.md 8d
+            # stay the numerator of `frac` (its storage-format rule), `frac_of_own_bytes` prices the 2 B that are moved
+            s16 = torch.round(tracks[0] * 32768.0).to(torch.int16)
+            legs = {}
+            for name, tp_on in (("no_true_peak", False), ("true_peak", True)):
+                k16 = run.kernel_stats([s16], rates, tp_on, False, 32, 100)
+                r16 = run.last_results[0][0]
+                ach = algo_bytes / (k16["scan_mean_ms"] * 1e-3) / 1e9
+                legs[name] = {"kernel_ms_mean": round(k16["scan_mean_ms"], 4), "kernel_ms_min": round(k16["scan_min_ms"], 4),
+                              "msamples_per_s": round(my_samples / (k16["scan_mean_ms"] * 1e-3) / 1e6, 1),
+                              "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                              "frac_of_own_bytes": round(ach / 2 / HBM_PEAK_GBS, 4),
+                              "loudness": r16["loudness"], "peak": r16["peak"]}
+            line["s16"] = dict(workload="the C2 / C3 buffer as interleaved int16 in HBM (691 200 000 B for 60 min): "
+                                        "lgd_scan_kernel<..., S16> / lgd_tp_kernel<..., S16>",
+                               dtype="f64 K-filter on int16 samples (x / 32768, ebur128_add_frames_short)",
+                               hbm_bytes_per_sample=2, **legs,
+                               identical_to_f32=bool(legs["no_true_peak"]["loudness"] == tr["loudness"] and
+                                                     legs["true_peak"]["peak"] == c3["peak"]))
+            del s16
         line["step_ms"] = run.step_times(sc.plan(tracks, rates, true_peak=False, album=False), 20)
         if not args.no_h2d:
             line["h2d_inclusive"] = h2d_inclusive(run, tracks[0], rates[0], True)

@@ -49,9 +49,16 @@ enum {
 
 typedef struct lgd_ctx lgd_ctx;
 
+/* PCM element formats (lgd_plan_formats).  LGD_PCM_S16 is the reference's own feed: scan.c:442 converts every
+ * decoded frame to interleaved int16 and hands it to ebur128_add_frames_short (scan.c:448), which scales by
+ * 1/32768.  The S16 kernel variants read those 2 bytes per sample from HBM as they are: half the memory and half
+ * the traffic of the f32 form, results bit-identical to the f32 form fed with k/32768. */
+enum { LGD_PCM_F32 = 0, LGD_PCM_S16 = 1 };
+
 /* one input file == one ebur128_state in the reference (scan.c:126) */
 typedef struct {
-  const float *pcm;  /* device pointer, interleaved f32, 16-byte aligned */
+  const float *pcm;  /* device pointer, interleaved f32 (or int16 behind the same pointer, see lgd_plan_formats),
+                        16-byte aligned */
   uint64_t frames;   /* frames (samples per channel) */
   uint32_t channels; /* 1..64; default libebur128 channel map by index */
   uint32_t rate;     /* Hz */
@@ -132,6 +139,13 @@ int lgd_set_param(lgd_ctx *ctx, const char *name, long value);
 /* Build the segment table + workspace for a batch of tracks (host work and
  * hipMalloc happen here, never in lgd_execute). */
 int lgd_plan(lgd_ctx *ctx, const lgd_track *tracks, uint32_t n_tracks, uint32_t flags);
+/* Element format of every track of the NEXT lgd_plan / lgd_plan_albums call (consumed by it): formats[t] is
+ * LGD_PCM_F32 or LGD_PCM_S16, n_tracks must match that plan's.  Without this call (or with a null array) every
+ * track is f32.  A track announced as S16 carries `const int16_t *` behind lgd_track::pcm (frames x channels
+ * interleaved, 16-byte aligned).  S16 is read directly for mono and stereo tracks at any rate; for more
+ * channels lgd_plan returns LGD_EUNSUP -- widen those with lgd_convert_s16 and announce them as f32.
+ * (ebur128_add_frames_short, scan.c:448.) */
+int lgd_plan_formats(lgd_ctx *ctx, const uint8_t *formats, uint32_t n_tracks);
 /* The same for a batch of several albums on one GPU (LGD_FLAG_ALBUM): track t belongs to
  * album album_of_track[t] (< n_albums, non-decreasing: the tracks of an album are
  * consecutive; an album may be empty).  One launch scans every track and reduces every

@@ -43,11 +43,13 @@ FLAG_ALBUM = 2
 FLAG_ALBUM_PART1 = 4
 
 # every symbol include/loudscan_device.h declares
+PCM_F32, PCM_S16 = 0, 1  # include/loudscan_device.h LGD_PCM_*
+
 DEVICE_SYMBOLS = [
     "lgd_create", "lgd_destroy", "lgd_last_error", "lgd_set_param", "lgd_plan", "lgd_execute",
     "lgd_fetch", "lgd_album_record1", "lgd_album_record2", "lgd_album_stage2",
     "lgd_album_stage3", "lgd_copy_subblock_energies", "lgd_last_kernel_ms",
-    "lgd_kernel_ms_stats", "lgd_plan_info", "lgd_album_join", "lgd_copy_channel_peaks", "lgd_plan_albums", "lgd_convert_s16",
+    "lgd_kernel_ms_stats", "lgd_plan_info", "lgd_album_join", "lgd_copy_channel_peaks", "lgd_plan_albums", "lgd_convert_s16", "lgd_plan_formats",
     "lgd_join", "lgd_scan_only_ms_stats",
 ]
 
@@ -81,6 +83,7 @@ def load():
     L.lgd_plan_albums.argtypes = [vp, C.POINTER(LgdTrack), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,
                                   C.c_uint32]
     L.lgd_convert_s16.argtypes = [vp, vp, C.c_uint64, vp]
+    L.lgd_plan_formats.argtypes = [vp, C.POINTER(C.c_uint8), C.c_uint32]
     L.lgd_execute.argtypes = [vp, vp]
     L.lgd_fetch.argtypes = [vp, C.POINTER(LgdTrackResult), C.POINTER(LgdAlbumResult)]
     L.lgd_album_record1.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]

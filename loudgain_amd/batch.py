@@ -20,6 +20,7 @@ import threading
 
 import numpy as np
 
+from . import _lib
 from . import gain as _gain
 
 # rgbpm2's table (bin/rgbpm2:57-75): extension -> loudgain options; READABLE = what
@@ -103,8 +104,15 @@ class _Staging:
             cap = max(n, 1)
             self.host = torch.empty(cap, dtype=torch.int16).pin_memory()
             self.dev16 = torch.empty(cap, dtype=torch.int16, device=self.device)
-            self.dev32 = torch.empty(cap, dtype=torch.float32, device=self.device)
+            self.dev32 = None
             self.cap = cap
+
+    def widened(self):
+        """the f32 twin: only batches with 3+ channel tracks need it (mono / stereo are scanned as S16)"""
+        import torch
+        if self.dev32 is None or self.dev32.numel() < self.cap:
+            self.dev32 = torch.empty(self.cap, dtype=torch.float32, device=self.device)
+        return self.dev32
 
 
 class LibraryScanner:
@@ -167,10 +175,14 @@ class LibraryScanner:
             st.dev16[:n_samples].copy_(st.host[:n_samples], non_blocking=True)
         self.scan_stream.wait_stream(self.copy_stream)
         L = self.sc.L
-        self.sc._chk(L.lgd_convert_s16(st.dev16.data_ptr(), st.dev32.data_ptr(), n_samples,
-                                       self.scan_stream.cuda_stream))
-        base = st.dev32.data_ptr()
-        tracks = [(base + 4 * off, frames, wi["channels"]) for _, _, wi, off, frames in table]
+        # mono / stereo tracks are scanned as the S16 they are (LGD_PCM_S16: what the reference feeds libebur128,
+        # scan.c:442-448); a batch with wider tracks is widened once and those tracks read from the f32 twin
+        base16, base32 = st.dev16.data_ptr(), 0
+        if any(wi["channels"] > 2 for _, _, wi, _, _ in table):
+            base32 = st.widened().data_ptr()
+            self.sc._chk(L.lgd_convert_s16(base16, base32, n_samples, self.scan_stream.cuda_stream))
+        tracks = [((base16 + 2 * off, frames, wi["channels"], _lib.PCM_S16) if wi["channels"] <= 2 else
+                   (base32 + 4 * off, frames, wi["channels"], _lib.PCM_F32)) for _, _, wi, off, frames in table]
         rates = [wi["rate"] for _, _, wi, _, _ in table]
         albums = [b for b, *_ in table]
         self.sc.plan(tracks, rates, true_peak=self.true_peak, albums=albums)

@@ -39,6 +39,7 @@ struct ebur128_state_internal {
   int device = 0;
   // the collected frames as interleaved f32 in HBM (a piece of an arena block)
   float *dev = nullptr;
+  bool dev_s16 = false;  // `dev` holds interleaved int16 (mono / stereo states fed by ebur128_add_frames_short)
   size_t dev_frames = 0;      // frames that are up there
   int block = -1;             // arena block the piece lives in
   // cached results for `scanned_frames` frames (true peak only if the plan had the interpolator)
@@ -158,7 +159,11 @@ int upload(ebur128_state *st) {
     d->dev = nullptr;
     d->block = -1;
   }
-  d->dev = arena_alloc((n ? n : 1) * sizeof(float), &d->block);
+  // frames from ebur128_add_frames_short stay S16 in HBM for mono / stereo states: the kernels' S16 variants read
+  // them as they are (LGD_PCM_S16) -- no widening pass, half the arena; wider states are widened on the GPU
+  const bool keep_s16 = !d->is_float && st->channels <= 2;
+  d->dev_s16 = keep_s16;
+  d->dev = arena_alloc((n ? n : 1) * (keep_s16 ? sizeof(short) : sizeof(float)), &d->block);
   if (!d->dev) return EBUR128_ERROR_NOMEM;
   const size_t esz = d->is_float ? sizeof(float) : sizeof(short);
   size_t piece = STAGE_BYTES / esz;
@@ -172,6 +177,9 @@ int upload(ebur128_state *st) {
     if (d->is_float) {
       memcpy(g_pinned[b], d->f32.data() + first, m * sizeof(float));
       ok = hipMemcpyAsync(d->dev + first, g_pinned[b], m * sizeof(float), hipMemcpyHostToDevice, g_stream) == hipSuccess;
+    } else if (keep_s16) {
+      memcpy(g_pinned[b], d->s16.data() + first, m * sizeof(short));
+      ok = hipMemcpyAsync((short *)d->dev + first, g_pinned[b], m * sizeof(short), hipMemcpyHostToDevice, g_stream) == hipSuccess;
     } else {
       memcpy(g_pinned[b], d->s16.data() + first, m * sizeof(short));
       ok = hipMemcpyAsync(g_dev_stage[b], g_pinned[b], m * sizeof(short), hipMemcpyHostToDevice, g_stream) == hipSuccess &&
@@ -208,9 +216,11 @@ int scan_states(const std::vector<ebur128_state *> &sts) {
   lgd_ctx *c = ctx_for(device);
   if (!c) return EBUR128_ERROR_NOMEM;
   std::vector<lgd_track> t(sts.size());
+  std::vector<uint8_t> fmt(sts.size());
   for (size_t i = 0; i < sts.size(); ++i) {
     const int rc = upload(sts[i]);
     if (rc) return rc;
+    fmt[i] = (uint8_t)(sts[i]->d->dev_s16 ? LGD_PCM_S16 : LGD_PCM_F32);
     t[i].pcm = sts[i]->d->dev;
     t[i].frames = sts[i]->d->frames;
     t[i].channels = sts[i]->channels;
@@ -219,7 +229,8 @@ int scan_states(const std::vector<ebur128_state *> &sts) {
   std::vector<lgd_track_result> r(sts.size());
   g_album_valid = false;
   // (the scan follows the uploads on the shim's stream; lgd_fetch waits for it)
-  if (lgd_plan(c, t.data(), (uint32_t)sts.size(), (tp ? LGD_FLAG_TRUE_PEAK : 0u) | LGD_FLAG_ALBUM) ||
+  if (lgd_plan_formats(c, fmt.data(), (uint32_t)sts.size()) ||
+      lgd_plan(c, t.data(), (uint32_t)sts.size(), (tp ? LGD_FLAG_TRUE_PEAK : 0u) | LGD_FLAG_ALBUM) ||
       lgd_execute(c, g_stream) || lgd_fetch(c, r.data(), &g_album))
     return EBUR128_ERROR_NOMEM;
   ++g_plans;

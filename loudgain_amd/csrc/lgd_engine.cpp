@@ -23,13 +23,13 @@
 
 extern "C" const int lgd_chunk_table[];
 extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic);
-extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, const LgdSeg *segs,
+extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, int s16, const LgdSeg *segs,
                                       int n_seg, hipStream_t s);
 extern "C" hipError_t lgd_launch_peak_reduce(const LgdTrackMeta *meta, int n_tracks, const float *peaks,
                                              float *hint, hipStream_t s);
 extern "C" int lgd_tp_instance(int chunk, int *u_out, int *ns_out);
 extern "C" int lgd_tp_magics(int chunk, int nch_wg, int tp, unsigned *magic_nch, unsigned *magic_ns, unsigned *magic_c);
-extern "C" hipError_t lgd_launch_tp(int u, int tp, int ns, const LgdSeg *segs, int n_seg, int rows_max,
+extern "C" hipError_t lgd_launch_tp(int u, int tp, int ns, int s16, const LgdSeg *segs, int n_seg, int rows_max,
                                     hipStream_t s);
 extern "C" hipError_t lgd_launch_track_epilogue(const LgdSlice *slices, int n_slices,
                                                 const LgdTrackMeta *meta, int n_tracks,
@@ -267,6 +267,7 @@ struct Group {  // tracks sharing (rate, channels, channels per workgroup): one 
   int chunk, tp;
   bool generic;
   bool strided;  // channel pairs of a wider interleaved stream (lgd_scan_kernel<.., STR>)
+  bool s16;      // its tracks' PCM is interleaved int16 (lgd_plan_formats), read by the S16 kernel variants
   LgdFilt F;
   size_t seg_begin, seg_count;
   int rows_max;  // most true-peak candidate rows (tiles x channels) of any of its segments
@@ -278,7 +279,7 @@ struct Group {  // tracks sharing (rate, channels, channels per workgroup): one 
 // launch, its 96 kHz tracks another (nine launches per group became four).  The segments are a second
 // descriptor array in this order (WorkSet::d_segs_tp).
 struct TpLaunch {
-  int u, tp, ns, rows_max;
+  int u, tp, ns, s16, rows_max;
   size_t seg_begin, seg_count;
 };
 // One lgd_scan_kernel launch: the groups that run the same kernel instance (chunk, waves per workgroup,
@@ -286,6 +287,7 @@ struct TpLaunch {
 // constants differ per segment (LgdSeg::filt).
 struct Launch {
   int chunk, nch, tp, mode;  // tp: some group of it has an interpolator (the kernel records chunk maxima)
+  int s16;                   // PCM element format of its groups' tracks (LGD_PCM_*)
   size_t seg_begin, seg_count;
   std::vector<size_t> groups;
 };
@@ -302,6 +304,8 @@ struct lgd_ctx {
   bool planned = false, executed = false;
   uint32_t flags = 0;
   std::vector<lgd_track> tracks;
+  std::vector<uint8_t> fmt;       // per track: LGD_PCM_* of this plan
+  std::vector<uint8_t> next_fmt;  // announced by lgd_plan_formats for the next plan
   std::vector<LgdTrackMeta> meta;
   std::vector<LgdSeg> segs;
   std::vector<LgdSeg> segs_tp;       // the interpolating segments once more, in true-peak launch order
@@ -311,7 +315,7 @@ struct lgd_ctx {
   std::vector<LgdAlbumMeta> albums;
   std::vector<Group> groups;
   uint64_t total_sb = 0, total_e = 0, total_st = 0, total_peak_floats = 0, pcm_bytes = 0,
-           warm_bytes = 0, rec1_len = 4, total_tp_rows = 0;
+           warm_bytes = 0, rec1_len = 4, total_tp_rows = 0, pcm_resident_bytes = 0;
   // device workspace.  Everything a scan writes exists twice (WorkSet): scans
   // alternate between the two sets and between two streams (see lgd_execute).
   struct WorkSet {
@@ -535,6 +539,17 @@ static int pick_chunk(long forced, int s100, unsigned nch, int tp) {
 extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
                                const uint32_t *album_of_track, uint32_t n_albums, uint32_t flags);
 
+extern "C" int lgd_plan_formats(lgd_ctx *c, const uint8_t *formats, uint32_t n) {
+  if (!c) return fail(LGD_EINVAL, "lgd_plan_formats: null context");
+  c->next_fmt.clear();
+  if (!formats || !n) return LGD_OK;  // back to "all f32"
+  for (uint32_t t = 0; t < n; ++t)
+    if (formats[t] != LGD_PCM_F32 && formats[t] != LGD_PCM_S16)
+      return fail(LGD_EINVAL, "lgd_plan_formats: track %u: unknown PCM format %u", t, (unsigned)formats[t]);
+  c->next_fmt.assign(formats, formats + n);
+  return LGD_OK;
+}
+
 extern "C" int lgd_plan(lgd_ctx *c, const lgd_track *tracks, uint32_t n, uint32_t flags) {
   return lgd_plan_albums(c, tracks, n, nullptr, 1, flags);
 }
@@ -562,8 +577,14 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   c->ranges.clear();
   c->slices.clear();
   c->groups.clear();
-  c->total_sb = c->total_e = c->total_st = c->total_peak_floats = c->pcm_bytes = c->warm_bytes = 0;
+  c->total_sb = c->total_e = c->total_st = c->total_peak_floats = c->pcm_bytes = c->warm_bytes = c->pcm_resident_bytes = 0;
   c->total_tp_rows = 0;
+  // PCM element formats of this plan's tracks (lgd_plan_formats, consumed here; none: all f32)
+  if (!c->next_fmt.empty() && c->next_fmt.size() != n)
+    return fail(LGD_EINVAL, "lgd_plan: lgd_plan_formats announced %zu tracks, the plan has %u", c->next_fmt.size(), n);
+  c->fmt.assign(n, (uint8_t)LGD_PCM_F32);
+  if (!c->next_fmt.empty()) c->fmt.swap(c->next_fmt);
+  c->next_fmt.clear();
 
   uint64_t total_ch = 0;
   if ((uint64_t)n * LGD_MAX_CHANNELS > 0x7fffffffull) return fail(LGD_EUNSUP, "too many tracks in one plan");
@@ -577,6 +598,9 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if (tr.frames && !tr.pcm) return fail(LGD_EINVAL, "track %u: null PCM pointer", t);
     if (((uintptr_t)tr.pcm) & 15)
       return fail(LGD_EINVAL, "track %u: PCM pointer must be 16-byte aligned", t);
+    if (c->fmt[t] == LGD_PCM_S16 && tr.channels > 2)
+      return fail(LGD_EUNSUP, "track %u: S16 PCM is read directly for mono / stereo tracks only (%u channels: widen with lgd_convert_s16)",
+                  t, tr.channels);
     LgdTrackMeta &m = c->meta[t];
     m.s100 = (int)((tr.rate + 5) / 10);
     m.nch = (int)tr.channels;
@@ -599,7 +623,8 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     c->total_sb += nsb;
     c->total_e += nsb * tr.channels;
     c->total_st += (uint64_t)m.n_st_slots;
-    c->pcm_bytes += tr.frames * tr.channels * 4ull;
+    c->pcm_bytes += tr.frames * tr.channels * 4ull;  // (algorithmic: 4 B per sample whatever the element format)
+    c->pcm_resident_bytes += tr.frames * tr.channels * (c->fmt[t] == LGD_PCM_S16 ? 2ull : 4ull);
   }
   {  // albums = runs of consecutive tracks; an album without tracks is an empty run
     uint32_t t = 0;
@@ -616,10 +641,9 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   // launch groups: tracks (or 16-channel groups of wide tracks) that share
   // (rate, channels of the stream, channels per workgroup) run in one launch
   struct Key {
-    unsigned rate, nch_total, g_nch;
+    unsigned rate, nch_total, g_nch, fmt;
     bool operator<(const Key &o) const {
-      return rate != o.rate ? rate < o.rate
-                            : (nch_total != o.nch_total ? nch_total < o.nch_total : g_nch < o.g_nch);
+      return std::tie(rate, nch_total, g_nch, fmt) < std::tie(o.rate, o.nch_total, o.g_nch, o.fmt);
     }
   };
   std::map<Key, size_t> group_of;
@@ -636,7 +660,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   // of a segment has to stay small against it).
   const uint64_t min_seg = (uint64_t)std::max<long>(4, 3 * c->p_warm_sb);
   const uint64_t max_seg = 48;
-  struct RC { unsigned rate, ch; bool operator<(const RC &o) const { return rate != o.rate ? rate < o.rate : ch < o.ch; } };
+  struct RC { unsigned rate, ch, fmt; bool operator<(const RC &o) const { return std::tie(rate, ch, fmt) < std::tie(o.rate, o.ch, o.fmt); } };
   std::map<RC, uint64_t> key_sb, key_seg;
   // Streams as stereo-shaped workgroups, one per channel pair (the last pair of an odd count
   // overlaps its neighbour): possible whenever a stereo chunk length divides the sub-block.  Every
@@ -677,7 +701,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     const unsigned ch = tracks[t].channels;
     const unsigned sw = strided_for(tracks[t].rate, ch);
     const uint64_t mult = sw ? (ch + sw - 1) / sw : 1;  // one segment set per pair / triple
-    key_sb[RC{tracks[t].rate, ch}] += (uint64_t)c->meta[t].n_sb * mult;
+    key_sb[RC{tracks[t].rate, ch, c->fmt[t]}] += (uint64_t)c->meta[t].n_sb * mult;
   }
   // The kernel instance a (rate, channels) key runs on: keys that share it share ONE launch
   // ("merge_launches" 1, default), and it is the launch that has to fill the GPU -- a plan of a few
@@ -685,12 +709,12 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   // own partial last round.  The segments of a launch are sized to equal numbers of TILES (a
   // sub-block is 1 tile at 48 kHz and C = 75, 4 at 192 kHz).
   struct LK {
-    int chunk; unsigned k; int mode; unsigned rate, ch;  // (rate, ch: 0 when launches merge)
+    int chunk; unsigned k; int mode; unsigned rate, ch, fmt;  // (rate, ch: 0 when launches merge)
     bool operator<(const LK &o) const {
-      return std::tie(chunk, k, mode, rate, ch) < std::tie(o.chunk, o.k, o.mode, o.rate, o.ch);
+      return std::tie(chunk, k, mode, rate, ch, fmt) < std::tie(o.chunk, o.k, o.mode, o.rate, o.ch, o.fmt);
     }
   };
-  auto launch_key = [&](unsigned rate, unsigned ch, unsigned g_nch) -> LK {
+  auto launch_key = [&](unsigned rate, unsigned ch, unsigned g_nch, unsigned fmt) -> LK {
     const unsigned sw = strided_for(rate, ch);
     const int tp_ = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(rate) : 0;
     const int s100_ = (int)((rate + 5) / 10);
@@ -698,14 +722,14 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
                    : (((g_nch <= 6 || g_nch == 8) && g_nch == ch) ? pick_chunk(c->p_chunk, s100_, g_nch, tp_) : 0);
     const int mode = sw ? 2 : (chunk ? 0 : 1);
     if (!chunk) chunk = 25;
-    return LK{chunk, g_nch, mode, c->p_merge ? 0u : rate, c->p_merge ? 0u : ch};
+    return LK{chunk, g_nch, mode, c->p_merge ? 0u : rate, c->p_merge ? 0u : ch, fmt};
   };
   struct ClassAcc { double tiles = 0.0, tps_min = 1e30; std::vector<RC> keys; };
   std::map<LK, ClassAcc> classes;
   for (const auto &kv : key_sb) {
     const unsigned str = strided_for(kv.first.rate, kv.first.ch);
     const unsigned k = str ? str : std::min<unsigned>(kv.first.ch, LGD_GROUP_CH);
-    const LK lk = launch_key(kv.first.rate, kv.first.ch, k);
+    const LK lk = launch_key(kv.first.rate, kv.first.ch, k, kv.first.fmt);
     const double tps = (double)((kv.first.rate + 5) / 10) / (64.0 * lk.chunk);  // tiles per sub-block
     ClassAcc &a = classes[lk];
     a.tiles += (double)kv.second * tps;
@@ -744,7 +768,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     LgdTrackMeta &m = c->meta[t];
     const int s100 = m.s100;
     const uint64_t nsb = (uint64_t)m.n_sb;
-    const uint64_t seg_t = key_seg[RC{tr.rate, tr.channels}];
+    const uint64_t seg_t = key_seg[RC{tr.rate, tr.channels, c->fmt[t]}];
     const uint64_t nseg = nsb ? (nsb + seg_t - 1) / seg_t : 1;
     m.n_seg = (int)nseg;
     m.peak_off = (long long)c->total_peak_floats;
@@ -764,7 +788,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     for (size_t pi = 0; pi < ch0s.size(); ++pi) {
       const unsigned ch0 = ch0s[pi];
       const unsigned g_nch = strided ? strided : std::min<unsigned>(LGD_GROUP_CH, tr.channels - ch0);
-      const Key key{tr.rate, tr.channels, g_nch};
+      const Key key{tr.rate, tr.channels, g_nch, c->fmt[t]};
       auto it = group_of.find(key);
       if (it == group_of.end()) {
         Group g;
@@ -773,6 +797,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         g.nch_total = tr.channels;
         g.tp = (flags & LGD_FLAG_TRUE_PEAK) ? interp_factor(g.rate) : 0;
         g.strided = strided != 0;
+        g.s16 = c->fmt[t] == LGD_PCM_S16;
         g.chunk = strided ? pick_chunk(c->p_chunk, s100, strided, g.tp)
                           : (((g_nch <= 6 || g_nch == 8) && g_nch == tr.channels)
                                  ? pick_chunk(c->p_chunk, s100, g_nch, g.tp) : 0);
@@ -806,14 +831,14 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         g.seg_begin = g.seg_count = 0;
         g.rows_max = 0;
         {
-          LK lk = launch_key(tr.rate, tr.channels, g_nch);
+          LK lk = launch_key(tr.rate, tr.channels, g_nch, c->fmt[t]);
           // (the kernel instance is what the group itself settled on)
           lk.chunk = g.chunk;
           lk.mode = g.strided ? 2 : (g.generic ? 1 : 0);
           auto li = launch_of.find(lk);
           if (li == launch_of.end()) {
             li = launch_of.emplace(lk, c->launches.size()).first;
-            c->launches.push_back(Launch{g.chunk, (int)g.nch, 0, lk.mode, 0, 0, {}});
+            c->launches.push_back(Launch{g.chunk, (int)g.nch, 0, lk.mode, g.s16 ? 1 : 0, 0, 0, {}});
           }
           g.launch = li->second;
           Launch &L = c->launches[g.launch];
@@ -875,7 +900,7 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
         }
         sg.peak_out = (float *)(uintptr_t)(m.peak_off + (long long)(sgi * 2ull * tr.channels));
         pair_segs[pi].push_back(sg);
-        if (sb0) c->warm_bytes += (uint64_t)warm_tiles * tile_f * g_nch * 4ull;
+        if (sb0) c->warm_bytes += (uint64_t)warm_tiles * tile_f * g_nch * (g.s16 ? 2ull : 4ull);
         sb0 += cnt;
       }
       pair_group = it->second;
@@ -922,12 +947,12 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     c->launches.swap(sorted);
   }
   {  // true-peak launches: the interpolating groups by kernel instance, most segments first
-    std::map<std::tuple<int, int, int>, std::vector<size_t>> by_inst;
+    std::map<std::tuple<int, int, int, int>, std::vector<size_t>> by_inst;
     for (size_t gi = 0; gi < c->groups.size(); ++gi)
       if (c->groups[gi].tp && c->groups[gi].seg_count)
-        by_inst[std::make_tuple(c->groups[gi].tp_u, c->groups[gi].tp, c->groups[gi].tp_ns)].push_back(gi);
+        by_inst[std::make_tuple(c->groups[gi].tp_u, c->groups[gi].tp, c->groups[gi].tp_ns, c->groups[gi].s16 ? 1 : 0)].push_back(gi);
     for (const auto &kv : by_inst) {
-      TpLaunch T{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), 0, c->segs_tp.size(), 0};
+      TpLaunch T{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), 0, c->segs_tp.size(), 0};
       for (size_t gi : kv.second) {
         const Group &g = c->groups[gi];
         T.rows_max = std::max(T.rows_max, g.rows_max);
@@ -1197,7 +1222,7 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
     const Launch &L = c->launches[k];
     const int lane = n_side ? (int)(k % (size_t)(n_side + 1)) : 0;
     hipStream_t gs = lane == 0 ? s : c->gstream[lane - 1];
-    HIPCHK(lgd_launch_scan(L.chunk, L.nch, L.tp ? 4 : 0, L.mode, w.d_segs + L.seg_begin, (int)L.seg_count, gs));
+    HIPCHK(lgd_launch_scan(L.chunk, L.nch, L.tp ? 4 : 0, L.mode, L.s16, w.d_segs + L.seg_begin, (int)L.seg_count, gs));
   }
   for (int i = 0; i < n_side; ++i) {
     HIPCHK(hipEventRecord(c->ev_gjoin[i], c->gstream[i]));
@@ -1218,7 +1243,7 @@ extern "C" int lgd_execute(lgd_ctx *c, void *hip_stream) {
 #ifndef LGD_FUSED_TP  // (experiment build: the scan kernel has evaluated the interpolator itself, make libloudscan_hip_fused.so)
   if (c->flags & LGD_FLAG_TRUE_PEAK)
     for (const TpLaunch &T : c->tp_launches)
-      HIPCHK(lgd_launch_tp(T.u, T.tp, T.ns, w.d_segs_tp + T.seg_begin, (int)T.seg_count, T.rows_max, s));
+      HIPCHK(lgd_launch_tp(T.u, T.tp, T.ns, T.s16, w.d_segs_tp + T.seg_begin, (int)T.seg_count, T.rows_max, s));
 #endif
   if (c->p_timing) HIPCHK(hipEventRecord(ev[1], s));
   // gating pass 1, pass 2, result records and loudness ranges of all tracks: one launch (the long short-term

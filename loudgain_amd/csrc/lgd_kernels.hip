@@ -70,6 +70,26 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LGD_GLOBAL __attribute__((address_space(1)))
 typedef const f32x4 LGD_GLOBAL *gvec_ptr;
 typedef const float LGD_GLOBAL *gflt_ptr;
+// PCM element formats.  f32 (scale 1.0, ebur128_add_frames_float) or the reference's own feed, interleaved S16
+// (scan.c:442-448, ebur128_add_frames_short: x / 32768).  The S16 variants widen at staging time to the INTEGER-valued
+// float and carry the factor 2^-15 (2^-30 for energies) to the few values they store: every operation in between is
+// linear, scaling by a power of two commutes with each rounding, so their results are bit-identical to the f32 variants'
+// on the same samples -- at half the HBM traffic (2 B per sample) and one v_cvt_f32_i32 per sample.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <bool S16> struct PcmIO {
+  typedef float elem;
+  typedef f32x4 vec;
+  static constexpr float peak_scale = 1.f;
+  static constexpr double energy_scale = 1.0;
+};
+template <> struct PcmIO<true> {
+  typedef short elem;
+  typedef s16x4 vec;
+  static constexpr float peak_scale = 1.f / 32768.f;
+  static constexpr double energy_scale = 1.0 / (32768.0 * 32768.0);
+};
+__device__ __forceinline__ f32x4 lgd_widen(const f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 lgd_widen(const s16x4 v) { return (f32x4){(float)v.x, (float)v.y, (float)v.z, (float)v.w}; }
 
 // ---------------------------------------------------------------- helpers ---
 // Wave-wide sums through the DPP cross-lane paths of the VALU (no LDS round trip
@@ -184,12 +204,16 @@ struct ScanCfg {
 // workgroups of the other channel pairs read the same lines through L2 / Infinity Cache.  Every
 // layout then runs the mono / stereo kernel's long chunks (a six-plane tile of C = 75 would not
 // fit LDS twice).
-template <int C, int G, int TP, bool WIDE = false, bool STR = false>
+template <int C, int G, int TP, bool WIDE = false, bool STR = false, bool S16 = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
                                                       G ? LGD_WAVE * G : (WIDE ? 1024 : 512)),
                           amdgpu_waves_per_eu(G ? (G > 2 ? 3 : 2) : (WIDE ? 4 : 2), 4))) void lgd_scan_kernel(
     const LgdSeg *__restrict__ segs, const int nch_rt) {
   using K = ScanCfg<C, TP>;
+  using IO = PcmIO<S16>;
+  typedef const typename IO::elem LGD_GLOBAL *pelem_ptr;
+  typedef const typename IO::vec LGD_GLOBAL *pvec_ptr;
+  static_assert(!(S16 && STR), "S16 PCM: planar / run-time-channel variants only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   // the per-(rate, chunk) constants live in constant memory: uniform loads from
@@ -288,9 +312,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // loads are issued before the current tile is computed (software prefetch,
   // NV x 16 B per lane in flight); tiles touching a track edge take the guarded
   // path, where frames outside [0, n_frames) read as zero.
-  f32x4 pf[K::NV];
+  typename IO::vec pf[K::NV];
 #pragma unroll
-  for (int i = 0; i < K::NV; ++i) pf[i] = (f32x4)(0.f);
+  for (int i = 0; i < K::NV; ++i) pf[i] = (typename IO::vec)(0);
   bool pf_valid = false;
 #define LGD_TILE_G0(kk) ((sg.f0 + (long long)(kk) * K::TILE_F - K::HALO) * nch - shift)
 #define LGD_PREFETCH(kk)                                                                \
@@ -301,11 +325,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     if (pf_valid) {                                                                     \
       /* uniform base per vector (scalar adds) + one per-lane offset: no 64-bit    */   \
       /* VALU address arithmetic, no per-load branches -> the loads stay batched   */   \
-      const gvec_ptr src_ = (gvec_ptr)(sg.pcm + g0_);                                   \
+      const pvec_ptr src_ = (pvec_ptr)((pelem_ptr)sg.pcm + g0_);                        \
       _Pragma("unroll") for (int i_ = 0; i_ < K::NV; ++i_) {                            \
         /* the base of every vector stays a scalar (opaque to the optimiser): SGPR-base   */ \
         /* + 32-bit lane offset addressing, no 64-bit VALU adds per load                */ \
-        gvec_ptr src_i_ = src_ + nthreads * i_;                                         \
+        pvec_ptr src_i_ = src_ + nthreads * i_;                                         \
         asm volatile("" : "+s"(src_i_));                                                \
         if (LGD_VEC_ALWAYS(i_) || tid + nthreads * i_ < nvec) pf[i_] = src_i_[(unsigned)tid]; \
       }                                                                                 \
@@ -419,32 +443,32 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 #pragma unroll
       for (int i = 0; i < K::NV; ++i) {
         const int idx = tid + nthreads * i;
-        if (LGD_VEC_ALWAYS(i) || idx < nvec) LGD_STORE_VEC(idx, pf[i]);
+        if (LGD_VEC_ALWAYS(i) || idx < nvec) LGD_STORE_VEC(idx, lgd_widen(pf[i]));
       }
       if constexpr (LL::PLANAR && G == 2 && LL::PAD == 0)
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the asm stores above
     } else if (grouped) {
       // a channel group of a wide stream: gather [frame][ch0 .. ch0 + nch) float by float
-      const gflt_ptr gp = (gflt_ptr)sg.pcm;
+      const pelem_ptr gp = (pelem_ptr)sg.pcm;
       const int nfl = (K::TILE_F + K::HALO) * nch;
       for (int i = tid; i < nfl; i += nthreads) {
         const int fr = i / nch, c = i - fr * nch;
         const long long f = tb - K::HALO + fr;
-        lds[i] = (f >= 0 && f < n_frames) ? gp[f * nch_tot + ch0 + c] : 0.f;
+        lds[i] = (f >= 0 && f < n_frames) ? (float)gp[f * nch_tot + ch0 + c] : 0.f;
       }
     } else if (!(dbg & 1) && !(dbg & 64)) {
       const long long g0 = LGD_TILE_G0(k);
-      const gflt_ptr gp = (gflt_ptr)sg.pcm;
+      const pelem_ptr gp = (pelem_ptr)sg.pcm;
       for (int i = tid; i < nvec; i += nthreads) {
         const long long g = g0 + 4LL * i;
         f32x4 v;
         if (g >= 0 && g + 3 < sg.n_floats) {
-          v = *(gvec_ptr)(sg.pcm + g);
+          v = lgd_widen(*(pvec_ptr)(gp + g));
         } else {
-          v.x = (g + 0 >= 0 && g + 0 < sg.n_floats) ? gp[g + 0] : 0.f;
-          v.y = (g + 1 >= 0 && g + 1 < sg.n_floats) ? gp[g + 1] : 0.f;
-          v.z = (g + 2 >= 0 && g + 2 < sg.n_floats) ? gp[g + 2] : 0.f;
-          v.w = (g + 3 >= 0 && g + 3 < sg.n_floats) ? gp[g + 3] : 0.f;
+          v.x = (g + 0 >= 0 && g + 0 < sg.n_floats) ? (float)gp[g + 0] : 0.f;
+          v.y = (g + 1 >= 0 && g + 1 < sg.n_floats) ? (float)gp[g + 1] : 0.f;
+          v.z = (g + 2 >= 0 && g + 2 < sg.n_floats) ? (float)gp[g + 2] : 0.f;
+          v.w = (g + 3 >= 0 && g + 3 < sg.n_floats) ? (float)gp[g + 3] : 0.f;
         }
         LGD_STORE_VEC(i, v);
       }
@@ -728,6 +752,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
       const float M = fmaxf(mc, mprev), S2 = fmaxf(pp, pprev);
       float bnd = fmaxf(fmaf(Fk->tp[30], S2, Fk->tp[31] * M), fmaf(Fk->tp[32], S2, Fk->tp[33] * M));
       if (skip) bnd = 0.f;  // (the neighbouring set owns this channel: its rows, not these, go to the true-peak kernel)
+      bnd *= IO::peak_scale;  // (S16 PCM: the tile holds integer-valued samples)
       // rounded UP to bf16 (a bound may only grow), into the 8 x 16-bit shift register of the last
       // tiles (stored every 8 tiles / behind the loop)
       {
@@ -798,7 +823,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
           const bool mine = rel >= 0 && rel < lps;
           acc += mine ? e : 0.0;
           if (k * LGD_WAVE + LGD_WAVE >= cur_q + lps) {  // `cur` ends in this tile
-            const double tot = wave_sum_f64(acc) * Fk->pb0sq;
+            const double tot = wave_sum_f64(acc) * Fk->pb0sq * IO::energy_scale;
             if (lane == 0 && cur < sg.n_sb)
               ((double LGD_GLOBAL *)sg.e_out)[(long long)(ch0 + ch) * sg.e_ch_stride + cur] = tot;
             acc = 0.0;
@@ -815,7 +840,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
         for (;;) {
           acc += (sb_l == cur ? e : 0.0) + (sb_l + 1 == cur ? e_next : 0.0);
           if (tile_end >= (unsigned)(cur + 1) * (unsigned)s100) {  // `cur` ends in this tile
-            const double tot = wave_sum_f64(acc) * Fk->pb0sq;
+            const double tot = wave_sum_f64(acc) * Fk->pb0sq * IO::energy_scale;
             if (lane == 0 && cur < sg.n_sb)
               ((double LGD_GLOBAL *)sg.e_out)[(long long)(ch0 + ch) * sg.e_ch_stride + cur] = tot;
             acc = 0.0;
@@ -847,7 +872,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   }
 #endif
   if (!skip) {
-    const float s = wave_max_f32(pk_s);
+    const float s = wave_max_f32(pk_s) * IO::peak_scale;
 #ifdef LGD_FUSED_TP
     const float s_tp = wave_max_f32(pk_tp);
 #endif
@@ -951,9 +976,13 @@ struct TpCfg {
 // rows the four rows of a wave make its life four times as long and the kernel's last, partly filled round of
 // waves with it: C3's 72 000 dense rows 0.306 -> 0.329 ms; its sweep over empty rows is a latency floor, 8 us,
 // that fewer waves do not lower.)
-template <int U, int TP, int NS, int LGD_TP_RPW>
+template <int U, int TP, int NS, int LGD_TP_RPW, bool S16 = false>
 __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const LgdSeg *__restrict__ segs) {
   using K = TpCfg<U, TP, NS>;
+  // (S16 PCM: the staged samples are integer-valued, 2^15 x the f32 variant's; thresholds are scaled up to
+  // them, the wave's maximum back down -- exact, see PcmIO)
+  using IO = PcmIO<S16>;
+  typedef const typename IO::elem LGD_GLOBAL *pelem_ptr;
   constexpr int HX = K::HX, LP = K::LP;
   constexpr int PK = (HX - 1) / 2;  // window index of the older of the two centre-tap samples of output 0
   // per wave: the ids of the chunks of the group being evaluated, and the staged frames (a group of accepted
@@ -1055,9 +1084,9 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const L
   if (mask == 0ull) continue;
   const int k = __builtin_amdgcn_readfirstlane((int)ri_[2]);
   const int chan = __builtin_amdgcn_readfirstlane((int)ri_[3]);
-  const float pthr = __int_as_float(__builtin_amdgcn_readfirstlane((int)ri_[4]));
+  const float pthr = __int_as_float(__builtin_amdgcn_readfirstlane((int)ri_[4])) * (1.f / IO::peak_scale);
   const long long tb = sg.f0 + (long long)k * tile_f;
-  const gflt_ptr pcm = (gflt_ptr)sg.pcm + chan;
+  const pelem_ptr pcm = (pelem_ptr)sg.pcm + chan;
   const int n_chunks = __popcll(mask);
   // the interpolator over one window: wv[i] = x[n0 - HX + i] -> m_[u] = max over the non-trivial phases of
   // |y(n0 + u)|, u < U
@@ -1123,20 +1152,20 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const L
     auto fetch_slab = [&](const int s) {
       const long long f_first = tb + (long long)s * (LGD_WAVE * LP) - HX;
       if (f_first >= 0 && f_first + (long long)K::NPRE_D * LGD_WAVE <= n_frames) {  // (wave-uniform) interior
-        gflt_ptr src = pcm + f_first * nch_tot;
+        pelem_ptr src = pcm + f_first * nch_tot;
         const unsigned lo = (unsigned)(lane * nch_tot);
 #pragma unroll
         for (int r = 0; r < K::NPRE_D; ++r) {
-          gflt_ptr src_r = src + (long long)(r * LGD_WAVE) * nch_tot;
+          pelem_ptr src_r = src + (long long)(r * LGD_WAVE) * nch_tot;
           asm volatile("" : "+s"(src_r));  // scalar base + 32-bit lane offset
-          pre[r] = src_r[lo];
+          pre[r] = (float)src_r[lo];
         }
       } else {
 #pragma unroll
         for (int r = 0; r < K::NPRE_D; ++r) {
           const long long f = f_first + r * LGD_WAVE + lane;
           const bool in = f >= 0 && f < n_frames;
-          pre[r] = in ? pcm[(in ? f : 0) * nch_tot] : 0.f;
+          pre[r] = in ? (float)pcm[(in ? f : 0) * nch_tot] : 0.f;
         }
       }
     };
@@ -1195,14 +1224,14 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const L
     auto fetch_chunk = [&](const int l, float &r0, float &r1) {
       const long long f = tb + (long long)l * C - HX + lane;  // (l: wave-uniform)
       if (interior) {
-        const gflt_ptr src = pcm + (tb + (long long)l * C - HX) * nch_tot;
+        const pelem_ptr src = pcm + (tb + (long long)l * C - HX) * nch_tot;
         const unsigned lo = (unsigned)(lane * nch_tot);
-        r0 = (lane < CH) ? src[lo] : 0.f;
-        r1 = (lane < n1) ? src[lo + (unsigned)(LGD_WAVE * nch_tot)] : 0.f;
+        r0 = (lane < CH) ? (float)src[lo] : 0.f;
+        r1 = (lane < n1) ? (float)src[lo + (unsigned)(LGD_WAVE * nch_tot)] : 0.f;
       } else {
         const bool in0 = lane < CH && f >= 0 && f < n_frames, in1 = lane < n1 && f + LGD_WAVE >= 0 && f + LGD_WAVE < n_frames;
-        r0 = in0 ? pcm[(in0 ? f : 0) * nch_tot] : 0.f;
-        r1 = in1 ? pcm[(in1 ? f + LGD_WAVE : 0) * nch_tot] : 0.f;
+        r0 = in0 ? (float)pcm[(in0 ? f : 0) * nch_tot] : 0.f;
+        r1 = in1 ? (float)pcm[(in1 ? f + LGD_WAVE : 0) * nch_tot] : 0.f;
       }
     };
     // evaluates the n flagged chunks staged in `buf` (ids in chunk_of)
@@ -1275,7 +1304,7 @@ __global__ __launch_bounds__(LGD_WAVE * LGD_TP_WAVES) void lgd_tp_kernel(const L
     }
     if (n_acc) run_group(n_acc);
   }
-  const float t = wave_max_f32_uniform(pk_t);
+  const float t = wave_max_f32_uniform(pk_t) * IO::peak_scale;
   if (t > 0.f && lane == 0)
     (void)__hip_atomic_fetch_max((unsigned LGD_GLOBAL *)sg.peak_out + nch_tot + chan,
                                  (unsigned)__float_as_int(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1311,17 +1340,17 @@ extern "C" size_t lgd_scan_lds_bytes(int chunk, int nch, int tp, int generic) {
 // without this (two per CU land 4/4/2/2 on a quarter of the CUs).
 __global__ void lgd_prime_kernel() {}
 
-template <int C, int G, int TP, bool WIDE = false, bool STR = false>
+template <int C, int G, int TP, bool WIDE = false, bool STR = false, bool S16 = false>
 static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, int nch,
                                 hipStream_t s) {
   const size_t lds_bytes = lgd_scan_lds_bytes(C, nch, TP, G == 0);
   if constexpr (G == 1 || G == 3) hipLaunchKernelGGL(lgd_prime_kernel, dim3(1024), dim3(LGD_WAVE), 0, s);
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)lgd_scan_kernel<C, G, TP, WIDE, STR>,
+    hipError_t e = hipFuncSetAttribute((const void *)lgd_scan_kernel<C, G, TP, WIDE, STR, S16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((lgd_scan_kernel<C, G, TP, WIDE, STR>), dim3(n_seg), dim3(LGD_WAVE * nch), lds_bytes, s,
+  hipLaunchKernelGGL((lgd_scan_kernel<C, G, TP, WIDE, STR, S16>), dim3(n_seg), dim3(LGD_WAVE * nch), lds_bytes, s,
                      segs, nch);
   return hipGetLastError();
 }
@@ -1357,15 +1386,28 @@ static hipError_t launch_scan_strided(int nch, int tp, const LgdSeg *segs, int n
 // exists for the shortest chunk only
 #define LGD_GENERIC_CHUNK 25
 template <int TP>
-static hipError_t launch_scan_generic(int nch, const LgdSeg *segs, int n_seg,
+static hipError_t launch_scan_generic(int nch, int s16, const LgdSeg *segs, int n_seg,
                                       hipStream_t s) {
+  if (s16) {  // S16 PCM: mono / stereo streams only (rates no fast chunk divides)
+    if (nch > 2) return hipErrorInvalidValue;
+    return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, false, false, true>(segs, n_seg, nch, s);
+  }
   if (nch <= 8) return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, false>(segs, n_seg, nch, s);
   return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, true>(segs, n_seg, nch, s);
 }
 
 template <int C>
-static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg,
+static hipError_t launch_scan_c(int nch, int tp, int s16, const LgdSeg *segs, int n_seg,
                                 hipStream_t s) {
+  if (s16) {  // interleaved S16 PCM (the reference's own feed): the mono / stereo kernels
+    if (nch == 1) {
+      if (tp) return launch_scan_t<C, 1, 4, false, false, true>(segs, n_seg, nch, s);
+      return launch_scan_t<C, 1, 0, false, false, true>(segs, n_seg, nch, s);
+    }
+    if (nch != 2) return hipErrorInvalidValue;
+    if (tp) return launch_scan_t<C, 2, 4, false, false, true>(segs, n_seg, nch, s);
+    return launch_scan_t<C, 2, 0, false, false, true>(segs, n_seg, nch, s);
+  }
   if (nch == 1) {
     if (tp == 4) return launch_scan_t<C, 1, 4>(segs, n_seg, nch, s);
     if (tp == 2) return launch_scan_t<C, 1, 4>(segs, n_seg, nch, s);
@@ -1403,7 +1445,7 @@ extern "C" int lgd_tp_instance(int chunk, int *u_out, int *ns_out) {
 
 // One launch for every segment that runs the kernel instance (U, TP, NS), whatever its chunk length and
 // channel count (LgdSeg carries them).  rows_max: most rows (tiles x channels) any of the segments has.
-extern "C" hipError_t lgd_launch_tp(int u, int tp, int ns, const LgdSeg *segs, int n_seg, int rows_max,
+extern "C" hipError_t lgd_launch_tp(int u, int tp, int ns, int s16, const LgdSeg *segs, int n_seg, int rows_max,
                                     hipStream_t s) {
   if (n_seg <= 0 || rows_max <= 0 || !tp) return hipSuccess;
 #ifndef LGD_TP_RPW_BIG
@@ -1415,7 +1457,10 @@ extern "C" hipError_t lgd_launch_tp(int u, int tp, int ns, const LgdSeg *segs, i
   if ((long long)rows_max >= (1ll << 26)) return hipErrorInvalidValue;  // (row / nch by umulhi: exact below 2^26)
 #define LGD_TP_CASE(u_, tp_, ns_)                                                         \
   if (u == u_ && tp == tp_ && ns == ns_) {                                                \
-    if (rpw != 1) hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, LGD_TP_RPW_BIG>), grid, block, 0, s, segs); \
+    if (s16) {                                                                            \
+      if (rpw != 1) hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, LGD_TP_RPW_BIG, true>), grid, block, 0, s, segs); \
+      else hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, 1, true>), grid, block, 0, s, segs); \
+    } else if (rpw != 1) hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, LGD_TP_RPW_BIG>), grid, block, 0, s, segs); \
     else hipLaunchKernelGGL((lgd_tp_kernel<u_, tp_, ns_, 1>), grid, block, 0, s, segs);   \
     return hipGetLastError();                                                             \
   }
@@ -1454,10 +1499,11 @@ extern "C" const int lgd_chunk_table[] = {25, 35, 45, 49, 50, 63, 70, 75, 0};
 // F: DEVICE pointer to the group's constants
 // generic: 0 = planar kernel of `nch` channels, 1 = run-time-channel kernel, 2 = channel pair /
 // single channel (nch = 2 / 1) of a wider interleaved stream
-extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, const LgdSeg *segs,
+extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, int s16, const LgdSeg *segs,
                                       int n_seg, hipStream_t s) {
   if (n_seg <= 0) return hipSuccess;
   if (generic == 2) {
+    if (s16) return hipErrorInvalidValue;  // (channel sets of wide streams: f32 PCM only)
     switch (chunk) {
       case 25: return launch_scan_strided<25>(nch, tp, segs, n_seg, s);
       case 35: return launch_scan_strided<35>(nch, tp, segs, n_seg, s);
@@ -1473,20 +1519,20 @@ extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, c
   if (nch < 1 || nch > 16) return hipErrorInvalidValue;
   if (generic) {
     if (chunk != LGD_GENERIC_CHUNK) return hipErrorInvalidValue;
-    if (tp == 4) return launch_scan_generic<4>(nch, segs, n_seg, s);
-    if (tp == 2) return launch_scan_generic<4>(nch, segs, n_seg, s);
-    return launch_scan_generic<0>(nch, segs, n_seg, s);
+    if (tp == 4) return launch_scan_generic<4>(nch, s16, segs, n_seg, s);
+    if (tp == 2) return launch_scan_generic<4>(nch, s16, segs, n_seg, s);
+    return launch_scan_generic<0>(nch, s16, segs, n_seg, s);
   }
   if (nch > 8 || nch == 7) return hipErrorInvalidValue;
   switch (chunk) {
-    case 25: return launch_scan_c<25>(nch, tp, segs, n_seg, s);
-    case 35: return launch_scan_c<35>(nch, tp, segs, n_seg, s);
-    case 45: return launch_scan_c<45>(nch, tp, segs, n_seg, s);
-    case 49: return launch_scan_c<49>(nch, tp, segs, n_seg, s);
-    case 50: return launch_scan_c<50>(nch, tp, segs, n_seg, s);
-    case 63: return launch_scan_c<63>(nch, tp, segs, n_seg, s);
-    case 70: return launch_scan_c<70>(nch, tp, segs, n_seg, s);
-    case 75: return launch_scan_c<75>(nch, tp, segs, n_seg, s);
+    case 25: return launch_scan_c<25>(nch, tp, s16, segs, n_seg, s);
+    case 35: return launch_scan_c<35>(nch, tp, s16, segs, n_seg, s);
+    case 45: return launch_scan_c<45>(nch, tp, s16, segs, n_seg, s);
+    case 49: return launch_scan_c<49>(nch, tp, s16, segs, n_seg, s);
+    case 50: return launch_scan_c<50>(nch, tp, s16, segs, n_seg, s);
+    case 63: return launch_scan_c<63>(nch, tp, s16, segs, n_seg, s);
+    case 70: return launch_scan_c<70>(nch, tp, s16, segs, n_seg, s);
+    case 75: return launch_scan_c<75>(nch, tp, s16, segs, n_seg, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -65,7 +65,8 @@ struct Track {
   int codec = 0;
   unsigned channels = 0, rate = 0;
   size_t frames = 0;
-  float *dev = nullptr;  // interleaved f32 in HBM (arena of its GPU, or borrowed)
+  float *dev = nullptr;  // interleaved f32 in HBM (arena of its GPU, or borrowed) -- or int16, see s16
+  bool s16 = false;      // the PCM stays resident as the interleaved S16 it arrived as (LGD_PCM_S16: mono / stereo)
   int gpu = 0;           // index into g_devs
   bool loaded = false;
 };
@@ -184,7 +185,11 @@ template <typename Fill>
 void upload(Track &t, size_t total, bool as_s16, Fill fill) {
   Dev &d = g_devs[t.gpu];
   HIPFATAL(hipSetDevice(d.hip_id));
-  t.dev = (float *)arena_alloc(d, (total ? total : 1) * sizeof(float));
+  // S16 input of a mono / stereo track stays S16 in HBM: the kernels' S16 variants read it as it is (what
+  // ebur128_add_frames_short is handed at scan.c:448) -- no widening pass, half the arena; wider layouts are
+  // widened to f32 on the GPU as before
+  t.s16 = as_s16 && t.channels <= 2;
+  t.dev = (float *)arena_alloc(d, (total ? total : 1) * (t.s16 ? sizeof(short) : sizeof(float)));
   // A piece is a whole number of FRAMES (and of 8 samples, which keeps every piece's start 16-B aligned for
   // the widening kernel): `fill` may come from a sequential reader that delivers whole frames, so a piece
   // that ended inside a frame would shift everything behind it (round 2 cut at 2^25 samples whatever the
@@ -198,7 +203,9 @@ void upload(Track &t, size_t total, bool as_s16, Fill fill) {
     d.turn ^= 1;
     if (d.ev_used[b]) HIPFATAL(hipEventSynchronize(d.ev[b]));  // the buffer's previous piece has left it
     fill(d.pinned[b], first, n);
-    if (as_s16) {
+    if (t.s16) {
+      HIPFATAL(hipMemcpyAsync((short *)t.dev + first, d.pinned[b], n * sizeof(short), hipMemcpyHostToDevice, d.stream));
+    } else if (as_s16) {
       HIPFATAL(hipMemcpyAsync(d.dev_stage[b], d.pinned[b], n * sizeof(short), hipMemcpyHostToDevice, d.stream));
       HIPFATAL(lgd_launch_s16_to_f32((const short *)d.dev_stage[b], t.dev + first, n, d.stream));
     } else {
@@ -232,6 +239,7 @@ void ensure_scanned() {
   const size_t nd = g_devs.size();
   g_res.assign(g_nb ? g_nb : 1, lgd_track_result());
   std::vector<std::vector<lgd_track>> lt(nd);
+  std::vector<std::vector<uint8_t>> lf(nd);  // LGD_PCM_* per track of a GPU's plan
   for (Dev &d : g_devs) d.tracks.clear();
   for (int i = 0; i < g_nb; ++i) {
     const Track &t = g_tracks[i];
@@ -241,6 +249,7 @@ void ensure_scanned() {
     x.channels = t.channels;
     x.rate = t.rate;
     lt[t.gpu].push_back(x);
+    lf[t.gpu].push_back((uint8_t)(t.s16 ? LGD_PCM_S16 : LGD_PCM_F32));
     g_devs[t.gpu].tracks.push_back(i);
   }
   for (Dev &d : g_devs) {
@@ -253,7 +262,8 @@ void ensure_scanned() {
   if (nd == 1) {
     Dev &d = g_devs[0];
     std::vector<lgd_track_result> r(g_nb ? g_nb : 1);
-    if (lgd_plan(d.ctx, lt[0].data(), (uint32_t)g_nb, LGD_FLAG_TRUE_PEAK | LGD_FLAG_ALBUM) ||
+    if (lgd_plan_formats(d.ctx, lf[0].data(), (uint32_t)g_nb) ||
+        lgd_plan(d.ctx, lt[0].data(), (uint32_t)g_nb, LGD_FLAG_TRUE_PEAK | LGD_FLAG_ALBUM) ||
         lgd_execute(d.ctx, d.stream) || lgd_fetch(d.ctx, r.data(), &g_album))
       fail("%s", lgd_last_error());
     copy_results(d.tracks, r);
@@ -268,13 +278,14 @@ void ensure_scanned() {
     double *p;
     uint64_t n;
     if (lgd_set_param(d.ctx, "album_slots", 0) || lgd_set_param(d.ctx, "album_world", (long)nd) ||
+        lgd_plan_formats(d.ctx, lf[k].data(), (uint32_t)lf[k].size()) ||
         lgd_plan(d.ctx, lt[k].data(), (uint32_t)lt[k].size(), flags) || lgd_album_record1(d.ctx, &p, &n))
       fail("%s", lgd_last_error());
     slots = std::max(slots, n - 4);
   }
   for (size_t k = 0; k < nd; ++k) {
     Dev &d = g_devs[k];
-    if (lgd_set_param(d.ctx, "album_slots", (long)slots) ||
+    if (lgd_set_param(d.ctx, "album_slots", (long)slots) || lgd_plan_formats(d.ctx, lf[k].data(), (uint32_t)lf[k].size()) ||
         lgd_plan(d.ctx, lt[k].data(), (uint32_t)lt[k].size(), flags) || lgd_execute(d.ctx, d.stream))
       fail("%s", lgd_last_error());  // (all GPUs now scan at the same time)
   }
@@ -403,6 +414,29 @@ extern "C" int scan_pcm_f32_device(const float *dev, size_t frames, unsigned cha
   if (hipPointerGetAttributes(&attr, dev) == hipSuccess)
     for (size_t k = 0; k < g_devs.size(); ++k)
       if (g_devs[k].hip_id == attr.device) { t.gpu = (int)k; break; }
+  return 0;
+}
+
+extern "C" int scan_pcm_s16_device(const short *dev, size_t frames, unsigned channels, unsigned rate,
+                                   unsigned index) {
+  if ((int)index >= g_nb) return -1;
+  begin_track(index, "<pcm_s16_device>", "wav", CODEC_PCM_S16LE, channels, rate, frames);
+  Track &t = g_tracks[index];
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, dev) == hipSuccess)
+    for (size_t k = 0; k < g_devs.size(); ++k)
+      if (g_devs[k].hip_id == attr.device) { t.gpu = (int)k; break; }
+  if (channels <= 2) {  // scanned where and as it lies
+    t.dev = reinterpret_cast<float *>(const_cast<short *>(dev));
+    t.s16 = true;
+    return 0;
+  }
+  // wider layouts: widened into the session's arena (the S16 kernels cover mono / stereo)
+  Dev &d = g_devs[t.gpu];
+  HIPFATAL(hipSetDevice(d.hip_id));
+  const size_t total = frames * channels;
+  t.dev = (float *)arena_alloc(d, (total ? total : 1) * sizeof(float));
+  if (total) HIPFATAL(lgd_launch_s16_to_f32(dev, t.dev, total, d.stream));
   return 0;
 }
 

@@ -54,24 +54,31 @@ class DeviceScanner:
         self._chk(self.L.lgd_set_param(self.ctx, name.encode(), int(value)))
 
     def plan(self, tracks, rates, true_peak=True, album=False, albums=None):
-        """tracks: device torch tensors [frames, channels] float32 contiguous, or
-        (ptr, frames, channels) tuples; rates: int or list of ints.
+        """tracks: device torch tensors [frames, channels] float32 (or int16: mono / stereo, read as they
+        are by the S16 kernels) contiguous, or (ptr, frames, channels[, LGD_PCM_*]) tuples; rates: int or list.
         albums: optional album index per track (non-decreasing): one launch scans all
         tracks and reduces every album; fetch() then returns a list of album results."""
         if isinstance(rates, int):
             rates = [rates] * len(tracks)
         arr = (LgdTrack * max(1, len(tracks)))()
+        fmts = (C.c_uint8 * max(1, len(tracks)))()
         for i, (t, r) in enumerate(zip(tracks, rates)):
             if isinstance(t, tuple):
-                ptr, frames, ch = t
+                ptr, frames, ch = t[:3]
+                fmts[i] = int(t[3]) if len(t) > 3 else _lib.PCM_F32
             else:
-                if t.dim() != 2 or not t.is_contiguous() or t.dtype.is_floating_point is False \
-                        or t.element_size() != 4:
-                    raise LoudscanError("track %d: need a contiguous [frames, channels] float32 tensor" % i)
+                # int16 tensors are the reference's own feed (ebur128_add_frames_short, scan.c:448): read as they are
+                s16 = t.dtype.is_floating_point is False and t.element_size() == 2 and t.dtype.is_signed
+                f32 = t.dtype.is_floating_point and t.element_size() == 4
+                if t.dim() != 2 or not t.is_contiguous() or not (s16 or f32):
+                    raise LoudscanError("track %d: need a contiguous [frames, channels] float32 or int16 tensor" % i)
                 if not t.is_cuda:
                     raise LoudscanError("track %d: PCM must be resident in HBM (device tensor)" % i)
                 ptr, frames, ch = t.data_ptr(), t.shape[0], t.shape[1]
+                fmts[i] = _lib.PCM_S16 if s16 else _lib.PCM_F32
             arr[i] = LgdTrack(ptr, frames, ch, int(r))
+        self._chk(self.L.lgd_plan_formats(self.ctx, fmts if any(fmts[i] for i in range(len(tracks))) else None,
+                                          len(tracks)))
         self._keep = tracks
         self.n_tracks = len(tracks)
         # album: False | True (all stages on this GPU) | "part1" (multi-GPU: the

@@ -28,7 +28,7 @@ SCAN_SYMBOLS = [
     "scan_album_has_different_containers", "scan_album_has_opus", "scan_file",
     "scan_get_track_result", "scan_get_album_peak", "scan_set_album_result",
     "scan_get_album_result", "scan_set_device", "scan_pcm_s16", "scan_pcm_f32",
-    "scan_pcm_f32_device", "scan_set_codec", "scan_wav_probe", "scan_wav_read_s16", "scan_set_devices", "scan_get_channel_peaks",
+    "scan_pcm_f32_device", "scan_pcm_s16_device", "scan_set_codec", "scan_wav_probe", "scan_wav_read_s16", "scan_set_devices", "scan_get_channel_peaks",
 ]
 
 
@@ -60,6 +60,7 @@ def _lib_scan():
         L.scan_pcm_s16.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
         L.scan_pcm_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
         L.scan_pcm_f32_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
+        L.scan_pcm_s16_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]
         L.scan_set_codec.argtypes = [C.c_uint, C.c_int, C.c_char_p]
         L.scan_wav_probe.argtypes = [C.c_char_p, C.POINTER(ScanWavInfo)]
         L.scan_wav_read_s16.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
@@ -92,8 +93,9 @@ def scan_pcm(pcm, rate, index):
         if not pcm.is_cuda:
             pcm = pcm.numpy()
         else:
-            assert pcm.is_contiguous() and pcm.element_size() == 4
-            return L.scan_pcm_f32_device(pcm.data_ptr(), pcm.shape[0], pcm.shape[1], int(rate), int(index))
+            assert pcm.is_contiguous() and pcm.element_size() in (2, 4)
+            fn = L.scan_pcm_s16_device if pcm.element_size() == 2 else L.scan_pcm_f32_device
+            return fn(pcm.data_ptr(), pcm.shape[0], pcm.shape[1], int(rate), int(index))
     import numpy as np
     pcm = np.ascontiguousarray(pcm)
     fn = L.scan_pcm_s16 if pcm.dtype == np.int16 else L.scan_pcm_f32
