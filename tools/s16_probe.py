@@ -14,6 +14,8 @@ for ch in [int(c) for c in os.environ.get("PROBE_CH", "2").split(",")]:
         out = []
         for tp in (False, True):
             sc = DeviceScanner(0); sc.set_param("overlap", 0)
+            for kv in [x for x in os.environ.get("PROBE_PARAMS", "").split(",") if x]:
+                sc.set_param(kv.split("=")[0], int(kv.split("=")[1]))
             sc.plan([buf], rate, true_peak=tp)
             s = torch.cuda.Stream()
             for _ in range(100): sc.execute(s)
@@ -21,7 +23,8 @@ for ch in [int(c) for c in os.environ.get("PROBE_CH", "2").split(",")]:
             for _ in range(30): sc.execute(s)
             (r,), _ = sc.fetch()
             ks = sc.kernel_ms_stats(30)
+            info = sc.plan_info()["segments"], sc.plan_info()["chunk"]
             out.append("%.4f ms %4.1f %% (%.6f LUFS, peak %.6f)" % (ks["scan_mean_ms"], frames * ch * 4 / ks["scan_mean_ms"] / 1e6 / 80.0, r["loudness"], r["peak"]))
             sc.close()
-        print(rate, ch, "ch", mat, name, "| no tp", out[0], "| tp", out[1], flush=True)
+        print(os.environ.get("PROBE_PARAMS", ""), rate, ch, "ch", mat, name, "segs", info, "| no tp", out[0], "| tp", out[1], flush=True)
     del pcm, s16
