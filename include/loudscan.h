@@ -86,10 +86,10 @@ int scan_pcm_f32(const float *interleaved, size_t frames, unsigned channels, uns
                  unsigned index);
 int scan_pcm_f32_device(const float *device_interleaved, size_t frames, unsigned channels,
                         unsigned rate, unsigned index);
-/* Interleaved S16 already resident in HBM (16-byte aligned, valid until scan_deinit): mono / stereo buffers are
- * scanned as they lie by the S16 kernel variants (no f32 copy exists at any time); wider layouts are widened into
- * the session's arena on the GPU.  Host S16 (scan_pcm_s16, 16-bit files through scan_file) stays S16 in HBM the
- * same way -- what the reference hands to ebur128_add_frames_short (scan.c:442-448). */
+/* Interleaved S16 already resident in HBM (16-byte aligned, valid until scan_deinit): scanned as it lies by the S16
+ * kernel variants (no f32 copy exists at any time).  Host S16 (scan_pcm_s16, every file through scan_file: the reader
+ * delivers the S16 that scan.c:442 converts to) stays S16 in HBM the same way -- what the reference hands to
+ * ebur128_add_frames_short (scan.c:448). */
 int scan_pcm_s16_device(const short *device_interleaved, size_t frames, unsigned channels,
                         unsigned rate, unsigned index);
 /* The RIFF/WAVE reader of scan_file on its own, for callers that batch their own uploads

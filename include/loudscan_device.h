@@ -142,9 +142,7 @@ int lgd_plan(lgd_ctx *ctx, const lgd_track *tracks, uint32_t n_tracks, uint32_t 
 /* Element format of every track of the NEXT lgd_plan / lgd_plan_albums call (consumed by it): formats[t] is
  * LGD_PCM_F32 or LGD_PCM_S16, n_tracks must match that plan's.  Without this call (or with a null array) every
  * track is f32.  A track announced as S16 carries `const int16_t *` behind lgd_track::pcm (frames x channels
- * interleaved, 16-byte aligned).  S16 is read directly for mono and stereo tracks at any rate; for more
- * channels lgd_plan returns LGD_EUNSUP -- widen those with lgd_convert_s16 and announce them as f32.
- * (ebur128_add_frames_short, scan.c:448.) */
+ * interleaved, 16-byte aligned); every layout and rate the f32 form covers (ebur128_add_frames_short, scan.c:448). */
 int lgd_plan_formats(lgd_ctx *ctx, const uint8_t *formats, uint32_t n_tracks);
 /* The same for a batch of several albums on one GPU (LGD_FLAG_ALBUM): track t belongs to
  * album album_of_track[t] (< n_albums, non-decreasing: the tracks of an album are

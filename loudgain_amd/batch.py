@@ -91,11 +91,11 @@ def pack_batches(sizes, capacity):
 
 
 class _Staging:
-    """One pinned host buffer + its device twin (S16) and the widened f32 PCM."""
+    """One pinned host buffer + its device twin (S16: scanned as it is)."""
 
     def __init__(self, device):
         self.device = device
-        self.host = self.dev16 = self.dev32 = None
+        self.host = self.dev16 = None
         self.cap = 0
 
     def ensure(self, n):
@@ -104,15 +104,7 @@ class _Staging:
             cap = max(n, 1)
             self.host = torch.empty(cap, dtype=torch.int16).pin_memory()
             self.dev16 = torch.empty(cap, dtype=torch.int16, device=self.device)
-            self.dev32 = None
             self.cap = cap
-
-    def widened(self):
-        """the f32 twin: only batches with 3+ channel tracks need it (mono / stereo are scanned as S16)"""
-        import torch
-        if self.dev32 is None or self.dev32.numel() < self.cap:
-            self.dev32 = torch.empty(self.cap, dtype=torch.float32, device=self.device)
-        return self.dev32
 
 
 class LibraryScanner:
@@ -156,7 +148,7 @@ class LibraryScanner:
         for b, i in enumerate(idxs):
             for f, wi in zip(tasks[i]["files"], infos[i]):
                 n = wi["frames"] * wi["channels"]
-                off = (off + 7) & ~7          # 16-byte aligned f32 tracks
+                off = (off + 7) & ~7          # 16-byte aligned S16 tracks
                 table.append([b, f, wi, off, wi["frames"]])
                 off += n
         st.ensure(off)
@@ -174,15 +166,9 @@ class LibraryScanner:
         with torch.cuda.stream(self.copy_stream):
             st.dev16[:n_samples].copy_(st.host[:n_samples], non_blocking=True)
         self.scan_stream.wait_stream(self.copy_stream)
-        L = self.sc.L
-        # mono / stereo tracks are scanned as the S16 they are (LGD_PCM_S16: what the reference feeds libebur128,
-        # scan.c:442-448); a batch with wider tracks is widened once and those tracks read from the f32 twin
-        base16, base32 = st.dev16.data_ptr(), 0
-        if any(wi["channels"] > 2 for _, _, wi, _, _ in table):
-            base32 = st.widened().data_ptr()
-            self.sc._chk(L.lgd_convert_s16(base16, base32, n_samples, self.scan_stream.cuda_stream))
-        tracks = [((base16 + 2 * off, frames, wi["channels"], _lib.PCM_S16) if wi["channels"] <= 2 else
-                   (base32 + 4 * off, frames, wi["channels"], _lib.PCM_F32)) for _, _, wi, off, frames in table]
+        # the tracks are scanned as the S16 they are (LGD_PCM_S16: what the reference feeds libebur128, scan.c:442-448)
+        base16 = st.dev16.data_ptr()
+        tracks = [(base16 + 2 * off, frames, wi["channels"], _lib.PCM_S16) for _, _, wi, off, frames in table]
         rates = [wi["rate"] for _, _, wi, _, _ in table]
         albums = [b for b, *_ in table]
         self.sc.plan(tracks, rates, true_peak=self.true_peak, albums=albums)

@@ -29,7 +29,6 @@
 #include "../../include/loudscan_device.h"
 #include "../../include/loudscan_ebur128.h"
 
-extern "C" hipError_t lgd_launch_s16_to_f32(const short *in, float *out, size_t n, hipStream_t s);
 
 struct ebur128_state_internal {
   std::vector<short> s16;   // collected frames (one of the two is used, by first call)
@@ -37,9 +36,9 @@ struct ebur128_state_internal {
   bool is_float = false;
   size_t frames = 0;          // collected
   int device = 0;
-  // the collected frames as interleaved f32 in HBM (a piece of an arena block)
+  // the collected frames in HBM, interleaved f32 or int16 as they came (a piece of an arena block)
   float *dev = nullptr;
-  bool dev_s16 = false;  // `dev` holds interleaved int16 (mono / stereo states fed by ebur128_add_frames_short)
+  bool dev_s16 = false;  // `dev` holds interleaved int16 (states fed by ebur128_add_frames_short)
   size_t dev_frames = 0;      // frames that are up there
   int block = -1;             // arena block the piece lives in
   // cached results for `scanned_frames` frames (true peak only if the plan had the interpolator)
@@ -68,7 +67,7 @@ struct Block {
 };
 std::vector<Block> g_blocks;
 hipStream_t g_stream = nullptr;
-void *g_pinned[2] = {nullptr, nullptr}, *g_dev_stage[2] = {nullptr, nullptr};
+void *g_pinned[2] = {nullptr, nullptr};
 hipEvent_t g_ev[2] = {nullptr, nullptr};
 bool g_ev_used[2] = {false, false};
 int g_turn = 0;
@@ -82,9 +81,8 @@ void drop_machinery() {
   if (g_stream) (void)hipStreamSynchronize(g_stream);
   for (int i = 0; i < 2; ++i) {
     if (g_pinned[i]) (void)hipHostFree(g_pinned[i]);
-    if (g_dev_stage[i]) (void)hipFree(g_dev_stage[i]);
     if (g_ev[i]) (void)hipEventDestroy(g_ev[i]);
-    g_pinned[i] = g_dev_stage[i] = nullptr;
+    g_pinned[i] = nullptr;
     g_ev[i] = nullptr;
     g_ev_used[i] = false;
   }
@@ -109,7 +107,7 @@ bool machinery() {
   if (g_stream) return true;
   if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return false;
   for (int i = 0; i < 2; ++i)
-    if (hipHostMalloc(&g_pinned[i], STAGE_BYTES) != hipSuccess || hipMalloc(&g_dev_stage[i], STAGE_BYTES) != hipSuccess ||
+    if (hipHostMalloc(&g_pinned[i], STAGE_BYTES) != hipSuccess ||
         hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess)
       return false;
   return true;
@@ -159,15 +157,15 @@ int upload(ebur128_state *st) {
     d->dev = nullptr;
     d->block = -1;
   }
-  // frames from ebur128_add_frames_short stay S16 in HBM for mono / stereo states: the kernels' S16 variants read
-  // them as they are (LGD_PCM_S16) -- no widening pass, half the arena; wider states are widened on the GPU
-  const bool keep_s16 = !d->is_float && st->channels <= 2;
+  // frames from ebur128_add_frames_short stay S16 in HBM: the kernels' S16 variants read them as they are
+  // (LGD_PCM_S16) -- no widening pass, half the arena
+  const bool keep_s16 = !d->is_float;
   d->dev_s16 = keep_s16;
   d->dev = arena_alloc((n ? n : 1) * (keep_s16 ? sizeof(short) : sizeof(float)), &d->block);
   if (!d->dev) return EBUR128_ERROR_NOMEM;
   const size_t esz = d->is_float ? sizeof(float) : sizeof(short);
   size_t piece = STAGE_BYTES / esz;
-  piece -= piece % 8;  // every piece starts 16-byte aligned in the f32 buffer
+  piece -= piece % 8;  // every piece starts 16-byte aligned in the device buffer
   for (size_t first = 0; first < n; first += piece) {
     const size_t m = std::min(piece, n - first);
     const int b = g_turn;
@@ -177,13 +175,9 @@ int upload(ebur128_state *st) {
     if (d->is_float) {
       memcpy(g_pinned[b], d->f32.data() + first, m * sizeof(float));
       ok = hipMemcpyAsync(d->dev + first, g_pinned[b], m * sizeof(float), hipMemcpyHostToDevice, g_stream) == hipSuccess;
-    } else if (keep_s16) {
-      memcpy(g_pinned[b], d->s16.data() + first, m * sizeof(short));
-      ok = hipMemcpyAsync((short *)d->dev + first, g_pinned[b], m * sizeof(short), hipMemcpyHostToDevice, g_stream) == hipSuccess;
     } else {
       memcpy(g_pinned[b], d->s16.data() + first, m * sizeof(short));
-      ok = hipMemcpyAsync(g_dev_stage[b], g_pinned[b], m * sizeof(short), hipMemcpyHostToDevice, g_stream) == hipSuccess &&
-           lgd_launch_s16_to_f32((const short *)g_dev_stage[b], d->dev + first, m, g_stream) == hipSuccess;
+      ok = hipMemcpyAsync((short *)d->dev + first, g_pinned[b], m * sizeof(short), hipMemcpyHostToDevice, g_stream) == hipSuccess;
     }
     if (!ok || hipEventRecord(g_ev[b], g_stream) != hipSuccess) return EBUR128_ERROR_NOMEM;
     g_ev_used[b] = true;

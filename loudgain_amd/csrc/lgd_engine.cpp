@@ -580,8 +580,11 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
   c->total_sb = c->total_e = c->total_st = c->total_peak_floats = c->pcm_bytes = c->warm_bytes = c->pcm_resident_bytes = 0;
   c->total_tp_rows = 0;
   // PCM element formats of this plan's tracks (lgd_plan_formats, consumed here; none: all f32)
-  if (!c->next_fmt.empty() && c->next_fmt.size() != n)
-    return fail(LGD_EINVAL, "lgd_plan: lgd_plan_formats announced %zu tracks, the plan has %u", c->next_fmt.size(), n);
+  if (!c->next_fmt.empty() && c->next_fmt.size() != n) {
+    const size_t announced = c->next_fmt.size();
+    c->next_fmt.clear();  // (an announcement is consumed by the plan call it was made for, whatever that call returns)
+    return fail(LGD_EINVAL, "lgd_plan: lgd_plan_formats announced %zu tracks, the plan has %u", announced, n);
+  }
   c->fmt.assign(n, (uint8_t)LGD_PCM_F32);
   if (!c->next_fmt.empty()) c->fmt.swap(c->next_fmt);
   c->next_fmt.clear();
@@ -598,9 +601,6 @@ extern "C" int lgd_plan_albums(lgd_ctx *c, const lgd_track *tracks, uint32_t n,
     if (tr.frames && !tr.pcm) return fail(LGD_EINVAL, "track %u: null PCM pointer", t);
     if (((uintptr_t)tr.pcm) & 15)
       return fail(LGD_EINVAL, "track %u: PCM pointer must be 16-byte aligned", t);
-    if (c->fmt[t] == LGD_PCM_S16 && tr.channels > 2)
-      return fail(LGD_EUNSUP, "track %u: S16 PCM is read directly for mono / stereo tracks only (%u channels: widen with lgd_convert_s16)",
-                  t, tr.channels);
     LgdTrackMeta &m = c->meta[t];
     m.s100 = (int)((tr.rate + 5) / 10);
     m.nch = (int)tr.channels;

@@ -213,7 +213,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   using IO = PcmIO<S16>;
   typedef const typename IO::elem LGD_GLOBAL *pelem_ptr;
   typedef const typename IO::vec LGD_GLOBAL *pvec_ptr;
-  static_assert(!(S16 && STR), "S16 PCM: planar / run-time-channel variants only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   // the per-(rate, chunk) constants live in constant memory: uniform loads from
@@ -338,14 +337,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
   // ---- strided variant: one frame of this workgroup's channels per lane and load
   constexpr int NFR = K::TILE_F + K::HALO;                              // frames staged per tile
   constexpr int NVS = STR ? (NFR + LGD_WAVE * (G ? G : 1) - 1) / (LGD_WAVE * (G ? G : 1)) : 1;
-  typedef const f32x2 LGD_GLOBAL *gvec2_ptr;
-  typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
-  typedef const f32x3u LGD_GLOBAL *gvec3_ptr;
-  f32x4 pfs[NVS];  // (.z only by channel triples and quads, .w only by quads)
-  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-  typedef const f32x4u LGD_GLOBAL *gvec4u_ptr;
+  // (element-aligned vector types: a channel set starts anywhere in a frame)
+  typedef typename IO::elem pel_t;
+  typedef pel_t pvec2a __attribute__((ext_vector_type(2)));                           // an aligned pair: one load
+  typedef const pvec2a LGD_GLOBAL *gvec2_ptr;
+  typedef pel_t pvec3u __attribute__((ext_vector_type(3), aligned(sizeof(pel_t))));
+  typedef const pvec3u LGD_GLOBAL *gvec3_ptr;
+  typename IO::vec pfs[NVS];  // (.z only by channel triples and quads, .w only by quads); raw elements: S16 is widened at staging
+  typedef pel_t pvec4u __attribute__((ext_vector_type(4), aligned(sizeof(pel_t))));
+  typedef const pvec4u LGD_GLOBAL *gvec4u_ptr;
 #pragma unroll
-  for (int i = 0; i < NVS; ++i) pfs[i] = (f32x4)(0.f);
+  for (int i = 0; i < NVS; ++i) pfs[i] = (typename IO::vec)(0);
   // (an aligned pair of channels is one 8-B load; odd channel counts take two dwords; a triple is
   // one 12-B load)
   const bool aligned2 = STR && G == 2 && !((nch_tot | ch0) & 1);
@@ -355,20 +357,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
     pf_valid = (fb_ >= 0) && (fb_ + NFR <= n_frames); /* uniform */                     \
     if (dbg & 1) pf_valid = false;                                                      \
     if (pf_valid) {                                                                     \
-      const gflt_ptr src_ = (gflt_ptr)sg.pcm + fb_ * nch_tot + ch0;                     \
+      const pelem_ptr src_ = (pelem_ptr)sg.pcm + fb_ * nch_tot + ch0;                   \
       const unsigned lo_ = (unsigned)(tid * nch_tot);                                   \
       _Pragma("unroll") for (int i_ = 0; i_ < NVS; ++i_) {                              \
-        gflt_ptr src_i_ = src_ + (long long)(nthreads * i_) * nch_tot;                  \
+        pelem_ptr src_i_ = src_ + (long long)(nthreads * i_) * nch_tot;                 \
         asm volatile("" : "+s"(src_i_));                                                \
         if (nthreads * (i_ + 1) <= NFR || tid + nthreads * i_ < NFR) {                  \
           if (G == 4) {                                                                 \
-            const f32x4u t_ = *(gvec4u_ptr)(src_i_ + lo_);                              \
-            pfs[i_] = (f32x4){t_.x, t_.y, t_.z, t_.w};                                  \
+            const pvec4u t_ = *(gvec4u_ptr)(src_i_ + lo_);                              \
+            pfs[i_] = (typename IO::vec){t_.x, t_.y, t_.z, t_.w};                       \
           } else if (G == 3) {                                                          \
-            const f32x3u t_ = *(gvec3_ptr)(src_i_ + lo_);                               \
+            const pvec3u t_ = *(gvec3_ptr)(src_i_ + lo_);                               \
             pfs[i_].x = t_.x; pfs[i_].y = t_.y; pfs[i_].z = t_.z;                       \
           } else if (G == 2 && aligned2) {                                              \
-            const f32x2 t_ = *(gvec2_ptr)(src_i_ + lo_);                                \
+            const pvec2a t_ = *(gvec2_ptr)(src_i_ + lo_);                               \
             pfs[i_].x = t_.x; pfs[i_].y = t_.y;                                         \
           } else {                                                                      \
             pfs[i_].x = src_i_[lo_];                                                    \
@@ -424,17 +426,18 @@ __global__ __attribute__((amdgpu_flat_work_group_size(G ? LGD_WAVE * G : 64,
 #pragma unroll
         for (int i = 0; i < NVS; ++i) {
           const int fr = tid + nthreads * i;
-          if (nthreads * (i + 1) <= NFR || fr < NFR) LGD_STORE_FRAME(fr, pfs[i].x, pfs[i].y, pfs[i].z, pfs[i].w);
+          if (nthreads * (i + 1) <= NFR || fr < NFR)
+            LGD_STORE_FRAME(fr, (float)pfs[i].x, (float)pfs[i].y, (float)pfs[i].z, (float)pfs[i].w);
         }
       } else if (!(dbg & 1) && !(dbg & 64)) {  // a tile at a track edge: frames outside the track are zero
-        const gflt_ptr gp = (gflt_ptr)sg.pcm + ch0;
+        const pelem_ptr gp = (pelem_ptr)sg.pcm + ch0;
         for (int fr = tid; fr < NFR; fr += nthreads) {
           const long long f = tb - K::HALO + fr;
           const bool in = f >= 0 && f < n_frames;
-          const float a = in ? gp[f * nch_tot] : 0.f;
-          const float b = (in && G >= 2) ? gp[f * nch_tot + 1] : 0.f;
-          const float c = (in && G >= 3) ? gp[f * nch_tot + 2] : 0.f;
-          const float d = (in && G >= 4) ? gp[f * nch_tot + 3] : 0.f;
+          const float a = in ? (float)gp[f * nch_tot] : 0.f;
+          const float b = (in && G >= 2) ? (float)gp[f * nch_tot + 1] : 0.f;
+          const float c = (in && G >= 3) ? (float)gp[f * nch_tot + 2] : 0.f;
+          const float d = (in && G >= 4) ? (float)gp[f * nch_tot + 3] : 0.f;
           LGD_STORE_FRAME(fr, a, b, c, d);
         }
       }
@@ -1356,79 +1359,64 @@ static hipError_t launch_scan_t(const LgdSeg *segs, int n_seg, int nch,
 }
 
 // channel pairs (or single channels) of a wider interleaved stream
-template <int C>
+template <int C, bool S16>
 static hipError_t launch_scan_strided(int nch, int tp, const LgdSeg *segs, int n_seg,
                                       hipStream_t s) {
   if (nch == 1) {
-    if (tp) return launch_scan_t<C, 1, 4, false, true>(segs, n_seg, nch, s);
-    return launch_scan_t<C, 1, 0, false, true>(segs, n_seg, nch, s);
+    if (tp) return launch_scan_t<C, 1, 4, false, true, S16>(segs, n_seg, nch, s);
+    return launch_scan_t<C, 1, 0, false, true, S16>(segs, n_seg, nch, s);
   }
   if (nch == 3) {
     if constexpr (C <= 50) {  // (three planes: the chunk lengths the three-channel kernel is built for)
-      if (tp) return launch_scan_t<C, 3, 4, false, true>(segs, n_seg, nch, s);
-      return launch_scan_t<C, 3, 0, false, true>(segs, n_seg, nch, s);
+      if (tp) return launch_scan_t<C, 3, 4, false, true, S16>(segs, n_seg, nch, s);
+      return launch_scan_t<C, 3, 0, false, true, S16>(segs, n_seg, nch, s);
     }
     return hipErrorInvalidValue;
   }
   if (nch == 4) {  // channel quads of a wider stream (7 channels: 0-3 | 3-6)
     if constexpr (C <= 50) {
-      if (tp) return launch_scan_t<C, 4, 4, false, true>(segs, n_seg, nch, s);
-      return launch_scan_t<C, 4, 0, false, true>(segs, n_seg, nch, s);
+      if (tp) return launch_scan_t<C, 4, 4, false, true, S16>(segs, n_seg, nch, s);
+      return launch_scan_t<C, 4, 0, false, true, S16>(segs, n_seg, nch, s);
     }
     return hipErrorInvalidValue;
   }
   if (nch != 2) return hipErrorInvalidValue;
-  if (tp) return launch_scan_t<C, 2, 4, false, true>(segs, n_seg, nch, s);
-  return launch_scan_t<C, 2, 0, false, true>(segs, n_seg, nch, s);
+  if (tp) return launch_scan_t<C, 2, 4, false, true, S16>(segs, n_seg, nch, s);
+  return launch_scan_t<C, 2, 0, false, true, S16>(segs, n_seg, nch, s);
 }
 
 // the generic kernel (any channel count, channel groups, any sub-block alignment)
 // exists for the shortest chunk only
 #define LGD_GENERIC_CHUNK 25
-template <int TP>
-static hipError_t launch_scan_generic(int nch, int s16, const LgdSeg *segs, int n_seg,
+template <int TP, bool S16>
+static hipError_t launch_scan_generic(int nch, const LgdSeg *segs, int n_seg,
                                       hipStream_t s) {
-  if (s16) {  // S16 PCM: mono / stereo streams only (rates no fast chunk divides)
-    if (nch > 2) return hipErrorInvalidValue;
-    return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, false, false, true>(segs, n_seg, nch, s);
-  }
-  if (nch <= 8) return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, false>(segs, n_seg, nch, s);
-  return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, true>(segs, n_seg, nch, s);
+  if (nch <= 8) return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, false, false, S16>(segs, n_seg, nch, s);
+  return launch_scan_t<LGD_GENERIC_CHUNK, 0, TP, true, false, S16>(segs, n_seg, nch, s);
 }
 
-template <int C>
-static hipError_t launch_scan_c(int nch, int tp, int s16, const LgdSeg *segs, int n_seg,
+// (tp 2 and 4 run the same scan kernel: it only records chunk bounds, with the factor's coefficients)
+template <int C, bool S16>
+static hipError_t launch_scan_c(int nch, int tp, const LgdSeg *segs, int n_seg,
                                 hipStream_t s) {
-  if (s16) {  // interleaved S16 PCM (the reference's own feed): the mono / stereo kernels
-    if (nch == 1) {
-      if (tp) return launch_scan_t<C, 1, 4, false, false, true>(segs, n_seg, nch, s);
-      return launch_scan_t<C, 1, 0, false, false, true>(segs, n_seg, nch, s);
-    }
-    if (nch != 2) return hipErrorInvalidValue;
-    if (tp) return launch_scan_t<C, 2, 4, false, false, true>(segs, n_seg, nch, s);
-    return launch_scan_t<C, 2, 0, false, false, true>(segs, n_seg, nch, s);
-  }
   if (nch == 1) {
-    if (tp == 4) return launch_scan_t<C, 1, 4>(segs, n_seg, nch, s);
-    if (tp == 2) return launch_scan_t<C, 1, 4>(segs, n_seg, nch, s);
-    return launch_scan_t<C, 1, 0>(segs, n_seg, nch, s);
+    if (tp) return launch_scan_t<C, 1, 4, false, false, S16>(segs, n_seg, nch, s);
+    return launch_scan_t<C, 1, 0, false, false, S16>(segs, n_seg, nch, s);
   }
   if (nch > 2) {  // 3 .. 6 or 8 planes per workgroup (2.1, quad, 5.0, 5.1, 7.1): the short chunks only
     if constexpr (C <= 50) {
 #define LGD_DISPATCH_G(g_)                                                              \
       if (nch == g_) {                                                                  \
-        if (tp == 4) return launch_scan_t<C, g_, 4>(segs, n_seg, nch, s);            \
-        if (tp == 2) return launch_scan_t<C, g_, 4>(segs, n_seg, nch, s);            \
-        return launch_scan_t<C, g_, 0>(segs, n_seg, nch, s);                         \
+        if (tp) return launch_scan_t<C, g_, 4, false, false, S16>(segs, n_seg, nch, s); \
+        return launch_scan_t<C, g_, 0, false, false, S16>(segs, n_seg, nch, s);         \
       }
       LGD_DISPATCH_G(3) LGD_DISPATCH_G(4) LGD_DISPATCH_G(5) LGD_DISPATCH_G(6) LGD_DISPATCH_G(8)
 #undef LGD_DISPATCH_G
     }
     return hipErrorInvalidValue;
   }
-  if (tp == 4) return launch_scan_t<C, 2, 4>(segs, n_seg, nch, s);
-  if (tp == 2) return launch_scan_t<C, 2, 4>(segs, n_seg, nch, s);
-  return launch_scan_t<C, 2, 0>(segs, n_seg, nch, s);
+  if (tp) return launch_scan_t<C, 2, 4, false, false, S16>(segs, n_seg, nch, s);
+  return launch_scan_t<C, 2, 0, false, false, S16>(segs, n_seg, nch, s);
 }
 
 // The kernel instance a chunk length runs on: U = frames per window step (the scan kernel's unroll of that
@@ -1502,37 +1490,26 @@ extern "C" const int lgd_chunk_table[] = {25, 35, 45, 49, 50, 63, 70, 75, 0};
 extern "C" hipError_t lgd_launch_scan(int chunk, int nch, int tp, int generic, int s16, const LgdSeg *segs,
                                       int n_seg, hipStream_t s) {
   if (n_seg <= 0) return hipSuccess;
-  if (generic == 2) {
-    if (s16) return hipErrorInvalidValue;  // (channel sets of wide streams: f32 PCM only)
-    switch (chunk) {
-      case 25: return launch_scan_strided<25>(nch, tp, segs, n_seg, s);
-      case 35: return launch_scan_strided<35>(nch, tp, segs, n_seg, s);
-      case 45: return launch_scan_strided<45>(nch, tp, segs, n_seg, s);
-      case 49: return launch_scan_strided<49>(nch, tp, segs, n_seg, s);
-      case 50: return launch_scan_strided<50>(nch, tp, segs, n_seg, s);
-      case 63: return launch_scan_strided<63>(nch, tp, segs, n_seg, s);
-      case 70: return launch_scan_strided<70>(nch, tp, segs, n_seg, s);
-      case 75: return launch_scan_strided<75>(nch, tp, segs, n_seg, s);
-      default: return hipErrorInvalidValue;
-    }
+#define LGD_BY_CHUNK(fn_, ...)                                                          \
+  switch (chunk) {                                                                      \
+    case 25: return s16 ? fn_<25, true>(__VA_ARGS__) : fn_<25, false>(__VA_ARGS__);     \
+    case 35: return s16 ? fn_<35, true>(__VA_ARGS__) : fn_<35, false>(__VA_ARGS__);     \
+    case 45: return s16 ? fn_<45, true>(__VA_ARGS__) : fn_<45, false>(__VA_ARGS__);     \
+    case 49: return s16 ? fn_<49, true>(__VA_ARGS__) : fn_<49, false>(__VA_ARGS__);     \
+    case 50: return s16 ? fn_<50, true>(__VA_ARGS__) : fn_<50, false>(__VA_ARGS__);     \
+    case 63: return s16 ? fn_<63, true>(__VA_ARGS__) : fn_<63, false>(__VA_ARGS__);     \
+    case 70: return s16 ? fn_<70, true>(__VA_ARGS__) : fn_<70, false>(__VA_ARGS__);     \
+    case 75: return s16 ? fn_<75, true>(__VA_ARGS__) : fn_<75, false>(__VA_ARGS__);     \
+    default: return hipErrorInvalidValue;                                               \
   }
+  if (generic == 2) LGD_BY_CHUNK(launch_scan_strided, nch, tp, segs, n_seg, s)
   if (nch < 1 || nch > 16) return hipErrorInvalidValue;
   if (generic) {
     if (chunk != LGD_GENERIC_CHUNK) return hipErrorInvalidValue;
-    if (tp == 4) return launch_scan_generic<4>(nch, s16, segs, n_seg, s);
-    if (tp == 2) return launch_scan_generic<4>(nch, s16, segs, n_seg, s);
-    return launch_scan_generic<0>(nch, s16, segs, n_seg, s);
+    if (tp) return s16 ? launch_scan_generic<4, true>(nch, segs, n_seg, s) : launch_scan_generic<4, false>(nch, segs, n_seg, s);
+    return s16 ? launch_scan_generic<0, true>(nch, segs, n_seg, s) : launch_scan_generic<0, false>(nch, segs, n_seg, s);
   }
   if (nch > 8 || nch == 7) return hipErrorInvalidValue;
-  switch (chunk) {
-    case 25: return launch_scan_c<25>(nch, tp, s16, segs, n_seg, s);
-    case 35: return launch_scan_c<35>(nch, tp, s16, segs, n_seg, s);
-    case 45: return launch_scan_c<45>(nch, tp, s16, segs, n_seg, s);
-    case 49: return launch_scan_c<49>(nch, tp, s16, segs, n_seg, s);
-    case 50: return launch_scan_c<50>(nch, tp, s16, segs, n_seg, s);
-    case 63: return launch_scan_c<63>(nch, tp, s16, segs, n_seg, s);
-    case 70: return launch_scan_c<70>(nch, tp, s16, segs, n_seg, s);
-    case 75: return launch_scan_c<75>(nch, tp, s16, segs, n_seg, s);
-    default: return hipErrorInvalidValue;
-  }
+  LGD_BY_CHUNK(launch_scan_c, nch, tp, segs, n_seg, s)
+#undef LGD_BY_CHUNK
 }

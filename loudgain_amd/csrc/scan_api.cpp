@@ -25,7 +25,6 @@
 #include "../../include/loudscan.h"
 #include "../../include/loudscan_device.h"
 
-extern "C" hipError_t lgd_launch_s16_to_f32(const short *in, float *out, size_t n, hipStream_t s);
 
 // FFmpeg AVCodecID values (recalled; FFmpeg headers are absent here).  The
 // reference only compares them for equality and against OPUS.
@@ -53,8 +52,7 @@ struct Dev {
   char *cur = nullptr;
   size_t cur_left = 0, next_block = ARENA_MIN;
   void *pinned[2] = {nullptr, nullptr};
-  void *dev_stage[2] = {nullptr, nullptr};  // S16 pieces waiting for the widening kernel
-  hipEvent_t ev[2] = {nullptr, nullptr};    // piece i of a buffer has left it (copy / widening done)
+  hipEvent_t ev[2] = {nullptr, nullptr};    // piece i of a buffer has left it (copy done)
   bool ev_used[2] = {false, false};
   int turn = 0;
   std::vector<int> tracks;  // file indices scanned on this GPU, ascending
@@ -120,7 +118,6 @@ void dev_open(Dev &d) {
   if (!d.stream) HIPFATAL(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
   for (int i = 0; i < 2; ++i) {
     if (!d.pinned[i]) HIPFATAL(hipHostMalloc(&d.pinned[i], STAGE_BYTES));
-    if (!d.dev_stage[i]) HIPFATAL(hipMalloc(&d.dev_stage[i], STAGE_BYTES));
     if (!d.ev[i]) HIPFATAL(hipEventCreateWithFlags(&d.ev[i], hipEventDisableTiming));
   }
 }
@@ -132,7 +129,6 @@ void dev_close(Dev &d) {
   for (void *b : d.blocks) (void)hipFree(b);
   for (int i = 0; i < 2; ++i) {
     if (d.pinned[i]) (void)hipHostFree(d.pinned[i]);
-    if (d.dev_stage[i]) (void)hipFree(d.dev_stage[i]);
     if (d.ev[i]) (void)hipEventDestroy(d.ev[i]);
   }
   if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -177,21 +173,20 @@ void begin_track(unsigned index, const char *name, const char *container, int co
   g_scanned = false;
 }
 
-// Streams `total` samples into the track's f32 buffer.  `fill(dst, first, n)` puts samples
-// [first, first + n) into a pinned buffer, as S16 (widened on the GPU: half the PCIe bytes, and
-// the grid scan.c:414 puts every input on) or as f32.  Two pinned buffers alternate: piece i + 1 is
+// Streams `total` samples into the track's buffer in HBM.  `fill(dst, first, n)` puts samples
+// [first, first + n) into a pinned buffer, as S16 (the grid scan.c:414 puts every input on: half the PCIe
+// bytes and half the HBM, scanned as it is) or as f32.  Two pinned buffers alternate: piece i + 1 is
 // produced while piece i crosses PCIe; nothing here waits for the GPU except for a buffer's turn.
 template <typename Fill>
 void upload(Track &t, size_t total, bool as_s16, Fill fill) {
   Dev &d = g_devs[t.gpu];
   HIPFATAL(hipSetDevice(d.hip_id));
-  // S16 input of a mono / stereo track stays S16 in HBM: the kernels' S16 variants read it as it is (what
-  // ebur128_add_frames_short is handed at scan.c:448) -- no widening pass, half the arena; wider layouts are
-  // widened to f32 on the GPU as before
-  t.s16 = as_s16 && t.channels <= 2;
+  // S16 input stays S16 in HBM: the kernels' S16 variants read it as it is (what ebur128_add_frames_short is
+  // handed at scan.c:448) -- no widening pass, half the arena
+  t.s16 = as_s16;
   t.dev = (float *)arena_alloc(d, (total ? total : 1) * (t.s16 ? sizeof(short) : sizeof(float)));
-  // A piece is a whole number of FRAMES (and of 8 samples, which keeps every piece's start 16-B aligned for
-  // the widening kernel): `fill` may come from a sequential reader that delivers whole frames, so a piece
+  // A piece is a whole number of FRAMES (and of 8 samples, which keeps every piece's start 16-B aligned):
+  // `fill` may come from a sequential reader that delivers whole frames, so a piece
   // that ended inside a frame would shift everything behind it (round 2 cut at 2^25 samples whatever the
   // channel count: 3 / 5 / 6 / 7-channel files longer than one piece got their later pieces 2 samples late
   // -- channels rotated, the last samples lost).
@@ -205,9 +200,6 @@ void upload(Track &t, size_t total, bool as_s16, Fill fill) {
     fill(d.pinned[b], first, n);
     if (t.s16) {
       HIPFATAL(hipMemcpyAsync((short *)t.dev + first, d.pinned[b], n * sizeof(short), hipMemcpyHostToDevice, d.stream));
-    } else if (as_s16) {
-      HIPFATAL(hipMemcpyAsync(d.dev_stage[b], d.pinned[b], n * sizeof(short), hipMemcpyHostToDevice, d.stream));
-      HIPFATAL(lgd_launch_s16_to_f32((const short *)d.dev_stage[b], t.dev + first, n, d.stream));
     } else {
       HIPFATAL(hipMemcpyAsync(t.dev + first, d.pinned[b], n * sizeof(float), hipMemcpyHostToDevice, d.stream));
     }
@@ -426,17 +418,8 @@ extern "C" int scan_pcm_s16_device(const short *dev, size_t frames, unsigned cha
   if (hipPointerGetAttributes(&attr, dev) == hipSuccess)
     for (size_t k = 0; k < g_devs.size(); ++k)
       if (g_devs[k].hip_id == attr.device) { t.gpu = (int)k; break; }
-  if (channels <= 2) {  // scanned where and as it lies
-    t.dev = reinterpret_cast<float *>(const_cast<short *>(dev));
-    t.s16 = true;
-    return 0;
-  }
-  // wider layouts: widened into the session's arena (the S16 kernels cover mono / stereo)
-  Dev &d = g_devs[t.gpu];
-  HIPFATAL(hipSetDevice(d.hip_id));
-  const size_t total = frames * channels;
-  t.dev = (float *)arena_alloc(d, (total ? total : 1) * sizeof(float));
-  if (total) HIPFATAL(lgd_launch_s16_to_f32(dev, t.dev, total, d.stream));
+  t.dev = reinterpret_cast<float *>(const_cast<short *>(dev));  // scanned where and as it lies
+  t.s16 = true;
   return 0;
 }
 

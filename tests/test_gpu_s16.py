@@ -91,8 +91,8 @@ def test_s16_bit_identical_to_f32(scanner, oracle, rate, nch, secs, kind, true_p
 
 
 def test_mixed_formats_in_one_plan(scanner, oracle):
-    """S16 and f32 tracks of several rates and layouts (5.1 stays f32) in one plan with an album."""
-    specs = [(48000, 2, 6.3, True), (48000, 2, 5.1, False), (44100, 1, 7.7, True), (48000, 6, 4.2, False),
+    """S16 and f32 tracks of several rates and layouts in one plan with an album."""
+    specs = [(48000, 2, 6.3, True), (48000, 2, 5.1, False), (44100, 1, 7.7, True), (48000, 6, 4.2, False), (48000, 6, 3.9, True),
              (96000, 2, 3.3, True), (44100, 2, 4.9, False), (48000, 1, 5.5, True), (11025, 2, 8.0, True)]
     pcm, devs = [], []
     for i, (rate, nch, secs, s16) in enumerate(specs):
@@ -124,20 +124,36 @@ def test_s16_segments_of_a_long_track(scanner):
         assert np.array_equal(ea, eb)
 
 
-def test_s16_rejects_wide_streams(scanner):
-    from loudgain_amd.device import LoudscanError
-    x = np.zeros((48000, 6), np.int16)
-    with pytest.raises(LoudscanError, match="mono / stereo"):
-        scanner.plan([to_dev(x)], 48000)
-    # the announcement was consumed: the next plan is f32 again
-    got, _ = scanner.scan([to_dev(np.zeros((48000, 6), np.float32))], 48000)
-    assert got[0]["n_blocks"] == 7
+WIDE = [(48000, 3), (48000, 4), (48000, 5), (48000, 6), (44100, 6), (96000, 6), (48000, 7), (48000, 8), (48000, 9),
+        (48000, 12), (48000, 16), (44100, 21), (48000, 24), (11025, 6), (22050, 3)]
+
+
+@pytest.mark.parametrize("strided", [1, 0, 2])
+@pytest.mark.parametrize("rate,nch", WIDE)
+def test_s16_wide_layouts(scanner, oracle, rate, nch, strided):
+    """3 .. 24 channels: planar kernels, channel pairs / triples / quads of the interleaved stream (aligned and
+    unaligned sets, overlapping sets), the run-time-channel kernel and its channel groups -- S16 against f32, bit for bit."""
+    frames = int(rate * 3.37)
+    x = synth.track_numpy(frames, nch, rate, seed=nch, step_s=0.7)
+    scanner.set_param("strided", strided)
+    try:
+        rs, _ = scanner.scan([to_dev(_as_s16(x))], rate, true_peak=True)
+        es, ps = scanner.subblock_energies(0), scanner.channel_peaks(0, nch)
+        rf, _ = scanner.scan([to_dev(x)], rate, true_peak=True)
+        ef, pf = scanner.subblock_energies(0), scanner.channel_peaks(0, nch)
+    finally:
+        scanner.set_param("strided", 1)
+    _same(rf[0], rs[0])
+    assert np.array_equal(ef, es)
+    assert np.array_equal(pf[0], ps[0]) and np.array_equal(pf[1], ps[1])
+    if strided == 1:
+        check_track(rs[0], oracle.scan_track(x, rate), tp=True, rate=rate)
 
 
 def test_scan_h_sessions_keep_s16(tmp_path):
     """scan.h level: S16 input (host, device, a 16-bit RIFF/WAVE file through scan_file) of mono / stereo tracks stays
     S16 in HBM; a session fed the same samples as f32 must report the same bits, track by track and for the album.
-    A 5.1 S16 device buffer is widened by the session (the S16 kernels cover mono / stereo)."""
+    5.1 likewise (channel triples of the S16 stream)."""
     import torch
     from loudgain_amd import scan
     from tests.test_gpu_scan_api import write_wav
@@ -180,7 +196,7 @@ def test_scan_h_sessions_keep_s16(tmp_path):
 
 
 def test_ebur128_shim_short_frames_stay_s16(oracle):
-    """ebur128_add_frames_short on mono / stereo states: scanned as S16, same bits as _float with k / 32768."""
+    """ebur128_add_frames_short: scanned as S16, same bits as _float with k / 32768."""
     from loudgain_amd import ebur128
     rate = 48000
     x = synth.track_numpy(rate * 6, 2, rate, seed=91, step_s=1.0)
@@ -197,3 +213,21 @@ def test_ebur128_shim_short_frames_stay_s16(oracle):
     assert abs(a.loudness_global() - ref["loudness"]) <= 1e-6
     a.close()
     b.close()
+
+
+def test_plan_formats_argument_checks(scanner):
+    import ctypes as C
+    from loudgain_amd.device import LoudscanError
+    L, ctx = scanner.L, scanner.ctx
+    bad = (C.c_uint8 * 1)(7)
+    assert L.lgd_plan_formats(ctx, bad, 1) != 0                      # unknown format code
+    two = (C.c_uint8 * 2)(1, 1)
+    assert L.lgd_plan_formats(ctx, two, 2) == 0
+    x = to_dev(np.zeros((4800, 2), np.int16))
+    from loudgain_amd._lib import LgdTrack
+    arr = (LgdTrack * 1)(LgdTrack(x.data_ptr(), 4800, 2, 48000))
+    assert L.lgd_plan(ctx, arr, 1, 0) != 0                           # announced for 2 tracks, planned 1
+    assert b"announced" in L.lgd_last_error()
+    assert L.lgd_plan_formats(ctx, None, 0) == 0                     # back to all-f32
+    with pytest.raises(LoudscanError):
+        scanner.plan([(x.data_ptr() + 2, 100, 2, 1)], 48000)         # misaligned pointer
