@@ -53,6 +53,9 @@ def parse_args(argv=None):
                     help="c2 / c3: steps = SURVEY 8d programme material; adversarial = constant-amplitude fs/4 "
                          "sine sampled on its peaks (no true-peak output can be pruned)")
     ap.add_argument("--no-c3", action="store_true", help="c2 on one GPU: skip the c3 object")
+    ap.add_argument("--pcm", default="f32", choices=["f32", "s16"],
+                    help="element format of the resident PCM: f32 (BASELINE.json's configs) or the same samples as the "
+                         "interleaved int16 the reference feeds libebur128 (scan.c:442-448), read by the S16 kernel variants")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer (PCIe-inclusive) figures")
     ap.add_argument("--no-c4", action="store_true", help="c2 on one GPU: skip the c4 object (the N = 1 anchor of the scaling series)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -272,6 +275,11 @@ def build_tracks(args, workload, rank, world, dev):
 
 
 def describe(args, workload, world, distributed):
+    d = _describe(args, workload, world, distributed)
+    return d if args.pcm == "f32" else d.replace("stereo f32", "stereo") + " [the samples as interleaved int16 in HBM, LGD_PCM_S16]"
+
+
+def _describe(args, workload, world, distributed):
     if workload in ("c2", "c3"):
         tp = " + 4x true peak" if workload == "c3" else ", no true peak"
         mat = "" if args.material == "steps" else " [%s material]" % args.material
@@ -515,6 +523,8 @@ def main():
     run = Runner(args, rank, world, local_rank)
     sc = run.sc
     tracks, rates = build_tracks(args, workload, rank, world, dev)
+    if args.pcm == "s16":
+        tracks = [torch.round(t * 32768.0).to(torch.int16) for t in tracks]
     torch.cuda.synchronize()
     true_peak = workload != "c2"
     album = workload in ("c4", "c5")
@@ -572,9 +582,10 @@ def main():
             "config": {
                 "workload": describe(args, workload, world, distributed),
                 "tracks_this_rank": len(tracks), "samples_per_step_all_ranks": total_samples,
-                "chunk": info["chunk"], "segments": info["segments"],
+                "chunk": info["chunk"], "segments": info["segments"], "pcm": args.pcm,
             },
-            "roofline": dict(roofline_block(algo_bytes, ks, dt / steps, traffic_from_profiles(workload), timing, kernels),
+            "roofline": dict(roofline_block(algo_bytes, ks, dt / steps,
+                                            traffic_from_profiles(workload) if args.pcm == "f32" else None, timing, kernels),
                              valu_bound=valu_bound_from_profiles(workload)),
             "result": {"loudness": tr["loudness"], "lra": tr["lra"], "peak": tr["peak"],
                        "n_abs": tr["n_abs"], "n_rel": tr["n_rel"], "n_st": tr["n_st"]},
@@ -595,7 +606,7 @@ def main():
             line["collective"] = collective
 
     # one GPU, c2: the reference's own semantics (true peak on) beside it, standard and adversarial material
-    if rank == 0 and world == 1 and workload == "c2" and not args.no_c3 and not distributed:
+    if rank == 0 and world == 1 and workload == "c2" and not args.no_c3 and not distributed and args.pcm == "f32":
         from loudgain_amd import synth
         c3steps = steps
         ks3 = run.kernel_stats(tracks, rates, True, False, 64, 300)
@@ -660,7 +671,8 @@ def main():
             line["h2d_inclusive"] = h2d_inclusive(run, tracks[0], rates[0], True)
     # one GPU, default line: config 4 too -- the workload `--gpus N` runs for N > 1 -- so that the driver's 1 / 2 / 4 / 8
     # series has its N = 1 point on the same workload (1000 tracks, 104 GB: fits one GPU's 288 GB)
-    if rank == 0 and world == 1 and workload == "c2" and not args.no_c4 and not distributed and args.workload == "auto":
+    if rank == 0 and world == 1 and workload == "c2" and not args.no_c4 and not distributed and args.workload == "auto" \
+            and args.pcm == "f32":
         del tracks
         sc.plan([], [], true_peak=False, album=False)   # (the engine lets go of the C2 buffer)
         torch.cuda.empty_cache()
