@@ -14,6 +14,7 @@ from loudgain_amd.device import DeviceScanner
 ap = argparse.ArgumentParser()
 ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--only", default="")
+ap.add_argument("--pcm", default="f32", choices=["f32", "s16"], help="s16: the samples as interleaved int16 in HBM (LGD_PCM_S16)")
 a = ap.parse_args()
 CASES = [(48000, 2), (44100, 2), (96000, 2), (192000, 2), (22050, 2), (32000, 2), (48000, 1), (44100, 1),
          (48000, 3), (48000, 4), (48000, 5), (44100, 5), (48000, 6), (44100, 6), (96000, 6), (192000, 6),
@@ -22,12 +23,15 @@ if a.only == "5.1":
     CASES = [c for c in CASES if c[1] == 6]
 elif a.only == "multi":
     CASES = [c for c in CASES if c[1] > 2]
+print("PCM resident as %s" % a.pcm)
 print("%-7s %-3s %-5s %-6s | %-28s | %-28s" % ("rate", "ch", "chunk", "segs", "no true peak: ms, % of 8 TB/s",
                                                "true peak: scan ms, scan+tp ms, %"))
 for rate, ch in CASES:
     frames = int(172800000 * 2 / ch)
     pcm = synth.track_torch(frames, ch, rate, seed=1, device="cuda")
-    nbytes = frames * ch * 4
+    if a.pcm == "s16":
+        pcm = torch.round(pcm * 32768.0).to(torch.int16)
+    nbytes = frames * ch * 4  # (algorithmic: 4 B per sample whatever the element format)
     row = []
     for tp, timing in ((False, 1), (True, 1), (True, 2)):
         sc = DeviceScanner(0)
