@@ -14,8 +14,9 @@
  *                          ebur128_loudness_range_multiple  scan.c:388
  *                          album peak loop                  scan.c:359-378
  *
- * PCM is interleaved f32 resident in HBM (scale 1.0 == ebur128_add_frames_float;
- * values on the S16 grid k/32768 reproduce the reference's S16 feed, scan.c:414).
+ * PCM is interleaved and resident in HBM: f32 (scale 1.0 == ebur128_add_frames_float; values on the
+ * S16 grid k/32768 reproduce the reference's S16 feed, scan.c:414) or that S16 feed itself
+ * (lgd_plan_formats, LGD_PCM_S16 == ebur128_add_frames_short: same results bit for bit, half the bytes).
  * Every call returns 0 on success or a negative LGD_E* code; lgd_last_error()
  * gives the text.  No call falls back to a CPU implementation.
  */

@@ -7,7 +7,7 @@
 // which only feeds the peaks -- SURVEY.md A.3: leftover frames are filtered
 // but never form a block).
 struct LgdSeg {
-  const float *pcm;      // track base (interleaved f32, 16-B aligned)
+  const float *pcm;      // track base (interleaved f32 -- or int16 for the S16 kernel variants --, 16-B aligned)
   long long n_floats;    // frames * channels of the whole track
   long long f0;          // first frame of this segment (multiple of s100)
   long long f_peak_end;  // tiles cover [f0, f_peak_end)

@@ -42,7 +42,7 @@ namespace {
 const size_t STAGE_BYTES = 64u << 20;
 const size_t ARENA_MIN = 64u << 20, ARENA_MAX = 1u << 30;
 
-// One GPU of the session: its engine context, its stream, an arena the tracks' f32 PCM lives in
+// One GPU of the session: its engine context, its stream, an arena the tracks' PCM (S16 or f32, as it came) lives in
 // until scan_deinit (one hipMalloc per ~GB, not per file), pinned double-buffered staging.
 struct Dev {
   int hip_id = 0;
