@@ -421,7 +421,14 @@ def test_fuzz_mixed_plans(scanner, oracle, seed):
     n_albums = int(rng.integers(1, 6))
     albums = sorted(int(a) for a in rng.integers(0, n_albums, size=12))
     albums[-1] = max(albums[-1], n_albums - 1) if rng.integers(2) else albums[-1]   # sometimes trailing empties
-    tracks, res = scanner.scan([to_dev(p) if p.size else torch_empty(p.shape[1]) for p in pcms],
+    # every track resident as f32 or, at random, as the interleaved int16 the reference feeds libebur128 (LGD_PCM_S16)
+    as_s16 = [bool(b) for b in np.random.default_rng(1000 + seed).integers(0, 2, size=12)]
+
+    def dev(p, s16):
+        if not p.size:
+            return torch_empty(p.shape[1], s16)
+        return to_dev(np.rint(p.astype(np.float64) * 32768.0).astype(np.int16)) if s16 else to_dev(p)
+    tracks, res = scanner.scan([dev(p, f) for p, f in zip(pcms, as_s16)],
                                [s[0] for s in specs], true_peak=tp, albums=albums)
     refs = [oracle.scan_track(p, s[0]) for p, s in zip(pcms, specs)]
     for got, ref, s in zip(tracks, refs, specs):
@@ -430,7 +437,7 @@ def test_fuzz_mixed_plans(scanner, oracle, seed):
     if tp:   # the pruning of the interpolator is exact on every one of these plans too: same floats with it off
         scanner.set_param("tp_prune", 0)
         try:
-            tracks0, res0 = scanner.scan([to_dev(p) if p.size else torch_empty(p.shape[1]) for p in pcms],
+            tracks0, res0 = scanner.scan([dev(p, not f) for p, f in zip(pcms, as_s16)],   # (and the other format each)
                                          [s[0] for s in specs], true_peak=True, albums=albums)
         finally:
             scanner.set_param("tp_prune", 1)
@@ -453,9 +460,9 @@ def test_fuzz_mixed_plans(scanner, oracle, seed):
             assert abs(album["peak"] - max(r["peak"] for r, al in zip(refs, albums) if al == a)) <= 1e-4
 
 
-def torch_empty(ch):
+def torch_empty(ch, s16=False):
     import torch
-    return torch.zeros((0, ch), dtype=torch.float32, device="cuda")
+    return torch.zeros((0, ch), dtype=torch.int16 if s16 else torch.float32, device="cuda")
 
 
 def test_large_album_range_selection(scanner):
