@@ -56,6 +56,14 @@ def test_bench_line_contract():
     assert 0 < c3["limited"]["frac"] <= c3["noise"]["frac"] * 1.05   # nothing prunable vs nearly everything
     assert d["step_ms"]["min"] <= d["step_ms"]["median"]
     # the N = 1 anchor of the scaling series: config 4 (here 40 short tracks) on the same line
+    # the same samples resident as interleaved int16 (LGD_PCM_S16): same results, reported beside the f32 line
+    s16 = d["s16"]
+    assert s16["identical_to_f32"] is True and s16["hbm_bytes_per_sample"] == 2
+    for leg in ("no_true_peak", "true_peak"):
+        assert 0 < s16[leg]["kernel_ms_min"] <= s16[leg]["kernel_ms_mean"]
+        assert abs(s16[leg]["frac"] - 2 * s16[leg]["frac_of_own_bytes"]) < 2e-4
+    assert s16["no_true_peak"]["loudness"] == d["result"]["loudness"] and s16["true_peak"]["peak"] == c3["peak"]
+    assert d["config"]["pcm"] == "f32"
     c4 = d["c4"]
     assert c4["workload"].startswith("C4") and c4["scaling"] == "strong" and c4["n_gpus"] == 1 and c4["value"] > 0
     assert abs(c4["value"] - c4["samples_per_step"] / (c4["ms_per_step"] * 1e-3) / 1e6) / c4["value"] < 1e-3
@@ -70,11 +78,13 @@ def test_bench_line_contract():
     assert mp["cores"] == 2 and mp["value"] > 0 and mp["model"] and mp["unit"] == "Msamples/s"
 
 
+@pytest.mark.parametrize("pcm", ["f32", "s16"])
 @pytest.mark.parametrize("wl,tracks", [("c4", 21), ("c5", 24)])
-def test_album_workloads(wl, tracks):
-    """configs 4 / 5 at reduced size (track lengths x 0.05): one GPU, album mode, true peak on."""
+def test_album_workloads(wl, tracks, pcm):
+    """configs 4 / 5 at reduced size (track lengths x 0.05): one GPU, album mode, true peak on; f32 and S16-resident PCM."""
     d = _bench("--workload", wl, "--tracks", str(tracks), "--track-scale", "0.05", "--steps", "5", "--warmup", "1",
-               "--no-cpu-baseline")
+               "--no-cpu-baseline", "--pcm", pcm)
+    assert d["config"]["pcm"] == pcm
     assert d["config"]["workload"].startswith(wl.upper()) and d["scaling"] == "strong" and d["n_gpus"] == 1
     assert d["config"]["tracks_this_rank"] == tracks
     samples = d["config"]["samples_per_step_all_ranks"]
